@@ -1,0 +1,138 @@
+/*
+ * sdod_hip.h -- kernel-level C ABI of the MI355X (gfx950) hot path.
+ *
+ * Every entry point takes plain device pointers, sizes and a HIP stream handle
+ * (void* == hipStream_t); no torch / C++ types cross this boundary.  Return value
+ * is 0 on success, otherwise a libsdod status code (include/libsdod.h) with a
+ * message retrievable through sdod_hip_last_error().
+ *
+ * What each group replaces in the reference (vaenyr/stable-diffusion-on-device):
+ *   - sdod_group_norm_*    : the `sdod::GroupNorm` / `sdod::ParameterlessGroupNorm` custom op whose
+ *                            schema is csrc/sdod_ops/config/group_norm.{xml,json} and whose Python
+ *                            surface is sdod/efficient_gn.py:9-30 (no kernel exists in the reference)
+ *   - sdod_gemm_f16, sdod_attention_f16, sdod_layer_norm_f16, ... : the arithmetic inside the opaque
+ *                            QNN graphs executed by QnnGraph::execute (csrc/libsdod/src/qnn_context.cpp:711-713)
+ *   - sdod_cfg_* / sdod_dpm_update / sdod_plms_* : the host-side CFG combine
+ *                            (qnn_context.cpp:1018-1081 via context.cpp:359-373) and DPMSolver::update
+ *                            (dpm_solver.cpp:136-181), moved on-device
+ *   - sdod_timestep_features: context.cpp:257-274
+ *   - sdod_image_to_u8      : context.cpp:392-395
+ *
+ * Layouts: activations are NHWC fp16 ("[N][H*W][C]", C contiguous); weights are [Cout][K] fp16 with
+ * K contiguous (conv3x3: K = (r*3+s)*Cin + c, i.e. KRSC); bias / norm parameters are fp32.
+ */
+#ifndef SDOD_HIP_H
+#define SDOD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifndef SDOD_API
+#define SDOD_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum sdod_act { SDOD_ACT_NONE = 0, SDOD_ACT_SILU = 1, SDOD_ACT_GELU = 2, SDOD_ACT_QUICK_GELU = 3 };
+enum sdod_dtype { SDOD_F16 = 0, SDOD_F32 = 1 };
+enum sdod_a_mode { SDOD_A_ROWS = 0, SDOD_A_CONV3X3 = 1 };
+
+/* out[M][N] = act(alpha * A[M][K] . W[N][K]^T + bias + row_bias) + residual        (fp16 in/out, fp32 acc)
+ * A is either a row-major matrix (SDOD_A_ROWS) or gathered on the fly from an NHWC image for a 3x3
+ * pad-1 convolution (SDOD_A_CONV3X3): row m = (img, oy, ox), k = (r, s, c); the image may be the
+ * channel-concatenation of two tensors (a, a2) and may be nearest-2x upsampled on the fly. */
+typedef struct sdod_gemm_desc {
+    const void* a;        /* fp16; rows: [M][lda]; conv: [n_img][h_in][w_in][c0] */
+    const void* a2;       /* conv only: second concat source [n_img][h_in][w_in][c1], or NULL */
+    const void* w;        /* fp16 [N][ldw] */
+    const void* bias;     /* fp32 [N] (or [M] if bias_on_m), may be NULL */
+    const void* row_bias; /* fp32 [M / rows_per_img][N] added per image, may be NULL */
+    const void* residual; /* fp16 [M][ldr], may be NULL */
+    void* out;            /* fp16 [M][ldo] */
+    void* workspace;      /* fp32 split-K slabs, >= split_k*M*N*4 bytes when split_k > 1 */
+    size_t workspace_bytes;
+    int M, N, K;
+    int lda, ldw, ldo, ldr;
+    int a_mode;
+    int n_img, h_in, w_in, c0, c1; /* conv geometry: input (pre-upsample) */
+    int stride;                    /* conv: 1 or 2 */
+    int upsample;                  /* conv: 1 = nearest 2x before the conv */
+    int rows_per_img;              /* for row_bias */
+    int act;
+    float alpha;
+    int bias_on_m;
+    int split_k;                   /* 0/1 = none; >1 = number of K slices (needs workspace) */
+    int tile;                      /* 0 = auto; else forces a tile config (see gemm.hip) */
+} sdod_gemm_desc;
+
+SDOD_API int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream);
+/* picks split_k / tile as the auto heuristic would; returns required workspace bytes */
+SDOD_API size_t sdod_gemm_workspace_bytes(const sdod_gemm_desc* d);
+
+/* GroupNorm over NHWC [N][HW][C] (optionally the channel concat of x (c0) and x2 (c1)), G groups,
+ * y = (x-mean)*rstd*w+b, optional SiLU.  dtype applies to x and y; weight/bias fp32 or NULL.
+ * workspace: >= sdod_group_norm_workspace_bytes(N, G) bytes of fp32 scratch. */
+SDOD_API size_t sdod_group_norm_workspace_bytes(int n, int groups);
+SDOD_API int sdod_group_norm_nhwc(const void* x, const void* x2, void* y, const float* weight, const float* bias,
+                                  int n, int hw, int c0, int c1, int groups, float eps, int silu, int dtype,
+                                  void* workspace, void* stream);
+
+/* LayerNorm over the last dim of fp16 [M][C] rows, fp32 weight/bias. */
+SDOD_API int sdod_layer_norm_f16(const void* x, void* y, const float* weight, const float* bias, int m, int c,
+                                 float eps, void* stream);
+
+/* Fused attention: out[b][q][h*D..] = softmax(scale * Q K^T (+causal mask)) V, never materialising scores.
+ * q: [B][Lq][ldq], k/v: [B][Lk][ldk]/[ldv], head h at column offset h*D.  D in {40, 64, 80, 160}. */
+SDOD_API int sdod_attention_f16(const void* q, const void* k, const void* v, void* out, int batch, int heads,
+                                int lq, int lk, int d, int ldq, int ldk, int ldv, int ldo, float scale, int causal,
+                                void* stream);
+
+/* Row softmax on fp16 [M][N] in place semantics allowed (y may equal x); fp32 math. */
+SDOD_API int sdod_softmax_rows_f16(const void* x, void* y, int m, int n, void* stream);
+
+/* Elementwise / glue (fp16 unless stated) */
+SDOD_API int sdod_geglu_f16(const void* x, void* y, int m, int c, void* stream); /* x:[M][2c] -> y = x[:, :c]*gelu(x[:, c:]) */
+SDOD_API int sdod_act_f16(const void* x, void* y, size_t n, int act, void* stream);
+SDOD_API int sdod_add_f16(const void* a, const void* b, void* y, size_t n, void* stream);
+SDOD_API int sdod_concat_channels_f16(const void* a, const void* b, void* y, size_t rows, int c0, int c1, void* stream);
+SDOD_API int sdod_im2col3x3_small_f16(const void* x, void* y, int n_img, int h, int w, int c, int kpad, void* stream);
+SDOD_API int sdod_nchw_f32_to_nhwc_f16(const float* x, void* y, int n, int c, int hw, float scale, void* stream);
+SDOD_API int sdod_nhwc_f16_to_nchw_f32(const void* x, float* y, int n, int c, int hw, void* stream);
+SDOD_API int sdod_embedding_f16(const int32_t* ids, const void* table, const void* pos, void* y, int rows, int seq,
+                                int c, void* stream);
+/* context.cpp:257-274: out[i][j]=cos(t_i*f_j), out[i][half+j]=sin(t_i*f_j), f_j=exp(-ln(1e4)*j/half); fp16 out */
+SDOD_API int sdod_timestep_features_f16(const float* t, void* y, int n, int dim, void* stream);
+
+/* Classifier-free guidance on the batched UNet output.  eps_nhwc: fp16 NHWC [2n][hw][c]; rows [0,n) are the
+ * unconditional half when uncond_first != 0 (ldm ordering), else the conditional half.  e_out: fp32 NCHW [n][c][hw].
+ *   mode 0: e = g*e_cond + (1-g)*e_uncond         -- the reference driver (context.cpp:359-373, libsdod.h:88)
+ *   mode 1: e = e_uncond + g*(e_cond - e_uncond)  -- ldm's PLMS/DDIM samplers (config 1's CPU reference) */
+SDOD_API int sdod_cfg_combine(const void* eps_nhwc, float* e_out, int n, int c, int hw, float guidance,
+                              int uncond_first, int mode, void* stream);
+/* DPM-Solver++(2M) update, dpm_solver.cpp:136-181, on fp32 device vectors of `count` elements, same operation
+ * order and no FMA contraction (bit-identical to the host loop for identical inputs):
+ *   y = (x - sigma_s*eps)/alpha_s ; x = sigma_ratio*x (+ c_prev*y_prev if order==2) + c_cur*y ; y_prev = y
+ * with sigma_ratio = sigma[s+1]/sigma[s], c_prev = alpha[s+1]*phi[s+1]*i2r[s+1],
+ * c_cur = -alpha[s+1]*phi[s+1] (order 1) or -alpha[s+1]*phi[s+1]*(1+i2r[s+1]) (order 2), all from the host tables. */
+SDOD_API int sdod_dpm_update(float* x, const float* eps, float* y_prev, size_t count, int order, float sigma_s,
+                             float alpha_s, float sigma_ratio, float c_prev, float c_cur, void* stream);
+/* ldm DDIM/PLMS step (eta=0): x0 = (x - sqrt(1-abar_t)*e)/sqrt(abar_t); x = sqrt(abar_prev)*x0 + dir_coef*e */
+SDOD_API int sdod_ddim_step_f32(float* x, const float* e, size_t count, float sqrt_one_minus_at, float sqrt_at,
+                                float sqrt_a_prev, float dir_coef, void* stream);
+/* out = (c0*e0 + c1*e1 + c2*e2 + c3*e3)/div, left to right (PLMS Adams-Bashforth combinations); e1..e3 may be NULL */
+SDOD_API int sdod_lincomb4_f32(float* out, const float* e0, const float* e1, const float* e2, const float* e3,
+                               float c0, float c1, float c2, float c3, float div, size_t count, void* stream);
+/* img: fp16 NHWC [n][hw][3] -> uint8 HWC per image, f = a*v+b, truncating cast:
+ *   mode 0: clamp(255*f, 0, 255)   (context.cpp:392-395; a=1,b=0 is the reference's already-[0,1] convention)
+ *   mode 1: 255*clamp(f, 0, 1)     (ldm txt2img with a=0.5, b=0.5) */
+SDOD_API int sdod_image_to_u8(const void* img, uint8_t* out, size_t count, float a, float b, int mode, void* stream);
+
+SDOD_API const char* sdod_hip_last_error(void);
+SDOD_API int sdod_hip_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int arch_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDOD_HIP_H */

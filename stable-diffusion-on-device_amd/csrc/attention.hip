@@ -1,0 +1,329 @@
+// attention.hip -- fused softmax(scale * Q K^T) V for the UNet's self/cross attention and CLIP's causal
+// attention on gfx950.  In the reference these are the `/attn*/to_*`, `/smax/`, `/MatMul` ops inside the
+// opaque UNet / text-encoder QNN graphs (analyze_results.py:69-79; executed at qnn_context.cpp:711-713).
+//
+// The score matrix (4096x4096 per head-batch at the 64x64 level) never touches HBM: a workgroup owns
+// 64*QT query rows of one (batch, head), walks K/V in 64-key tiles staged through LDS (register
+// prefetch, double-buffered, one barrier per tile) and keeps an online softmax in registers.
+//
+// wave64 / MFMA mapping (v_mfma_f32_16x16x32_f16), chosen so that NO cross-lane data movement is needed
+// between the two matrix products:
+//   * S^T = K . Q^T  (K rows are the MFMA "A" operand, Q rows the "B" operand): lane l ends up with the
+//     scores of ONE query (column l&15) against keys 16*t + 4*(l>>4) + r  -> the row max / row sum are
+//     in-lane reductions plus two xor-shuffles (16, 32);
+//   * O^T = V^T . P^T: the P registers a lane already holds ARE its B-operand fragment (keys on the
+//     contraction axis), and V^T fragments come from the row-major V tile through the gfx950
+//     transposed LDS read ds_read_b64_tr_b16 (4 keys x 16 columns per 16-lane group);
+//   * O^T keeps the query on the lane, so the online-softmax rescale is a per-lane scalar multiply.
+// Head dims 40/80/160 (SD v1) and 64 (CLIP, SD v2) are zero-padded in LDS to the MFMA granularity.
+#include "common.h"
+#include "sdod_hip.h"
+#include "host_util.h"
+
+#include <cstdlib>
+
+namespace {
+
+struct AttnP {
+    const f16* q;
+    const f16* k;
+    const f16* v;
+    f16* out;
+    int B, H, Lq, Lk;
+    int ldq, ldk, ldv, ldo;
+    float scale_log2;
+    int causal;
+};
+
+typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) short4v* lds_short4_ptr;
+
+constexpr int odd16(int dv) { // smallest 16*odd >= dv  (V row stride in halves: 32*odd bytes, conflict-free tr reads)
+    int s = (dv + 15) / 16;
+    if ((s & 1) == 0) s += 1;
+    return s * 16;
+}
+
+template <int D, int QT, bool TR>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
+    constexpr int DP = ((D + 31) / 32) * 32; // QK^T contraction, padded to MFMA K=32
+    constexpr int KSTEPS = DP / 32;
+    constexpr int DV = ((D + 15) / 16) * 16; // PV output columns, padded to 16
+    constexpr int NDT = DV / 16;
+    constexpr int KSTR = DP + 8;             // K tile row stride (halves)
+    constexpr int VSTR = odd16(DV);          // V tile row stride (halves)
+    constexpr int KT = 64;                   // keys per tile
+    constexpr int DC = D / 8;                // 16-byte chunks per K/V row
+    constexpr int LD_IT = (KT * DC + 255) / 256;
+    constexpr int STAGE = KT * (KSTR + VSTR);
+    static_assert(D % 8 == 0, "head dim must be a multiple of 8");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    f16* smem = reinterpret_cast<f16*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int g = lane >> 4;   // lane group 0..3
+    const int li = lane & 15;  // index inside the group
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q_block = blockIdx.x * (64 * QT);
+
+    const f16* kbase = p.k + (size_t)b * p.Lk * p.ldk + h * D;
+    const f16* vbase = p.v + (size_t)b * p.Lk * p.ldv + h * D;
+
+    // zero the padded columns of both stages once (they are never overwritten by the staging stores)
+    {
+        constexpr int KPADC = (DP - D) / 8, VPADC = (DV - D) / 8;
+        for (int st = 0; st < 2; ++st) {
+            f16* sK = smem + st * STAGE;
+            f16* sV = sK + KT * KSTR;
+            if (KPADC > 0)
+                for (int idx = tid; idx < KT * KPADC; idx += 256) {
+                    const int row = idx / (KPADC > 0 ? KPADC : 1), ch = idx - row * KPADC;
+                    *reinterpret_cast<f16x8*>(sK + row * KSTR + D + ch * 8) = zero8();
+                }
+            if (VPADC > 0)
+                for (int idx = tid; idx < KT * VPADC; idx += 256) {
+                    const int row = idx / (VPADC > 0 ? VPADC : 1), ch = idx - row * VPADC;
+                    *reinterpret_cast<f16x8*>(sV + row * VSTR + D + ch * 8) = zero8();
+                }
+        }
+    }
+
+    // Q fragments stay in registers for the whole kernel
+    f16x8 qf[QT][KSTEPS];
+    int qrow[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        qrow[t] = q_block + wave * (16 * QT) + t * 16 + li;
+        const f16* qp = p.q + ((size_t)b * p.Lq + qrow[t]) * p.ldq + h * D;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int d0 = ks * 32 + g * 8;
+            qf[t][ks] = (qrow[t] < p.Lq && d0 + 8 <= D) ? ldg8(qp + d0) : zero8();
+        }
+    }
+
+    int kend = p.Lk;
+    if (p.causal) kend = min(p.Lk, q_block + 64 * QT);
+    const int NT = (kend + KT - 1) / KT;
+
+    f16x8 rk[LD_IT], rv[LD_IT];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < LD_IT; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / DC, ch = idx - row * DC;
+            const int key = t * KT + row;
+            const bool ok = (idx < KT * DC) && (key < p.Lk);
+            rk[i] = ok ? ldg8(kbase + (size_t)key * p.ldk + ch * 8) : zero8();
+            rv[i] = ok ? ldg8(vbase + (size_t)key * p.ldv + ch * 8) : zero8();
+        }
+    };
+    auto store_tile = [&](int st) {
+        f16* sK = smem + st * STAGE;
+        f16* sV = sK + KT * KSTR;
+#pragma unroll
+        for (int i = 0; i < LD_IT; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / DC, ch = idx - row * DC;
+            if (idx < KT * DC) {
+                *reinterpret_cast<f16x8*>(sK + row * KSTR + ch * 8) = rk[i];
+                *reinterpret_cast<f16x8*>(sV + row * VSTR + ch * 8) = rv[i];
+            }
+        }
+    };
+
+    f32x4 o[QT][NDT];
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m_run[t] = -1e30f;
+        l_run[t] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    if (NT > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < NT; ++t) {
+        const int cur = t & 1;
+        const bool has_next = t + 1 < NT;
+        if (has_next) load_tile(t + 1);
+
+        const f16* sK = smem + cur * STAGE;
+        const f16* sV = sK + KT * KSTR;
+
+        // ---- S^T = K . Q^T
+        f32x4 s[QT][4];
+#pragma unroll
+        for (int a = 0; a < QT; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f16x8 kf = *reinterpret_cast<const f16x8*>(sK + (c * 16 + li) * KSTR + ks * 32 + g * 8);
+#pragma unroll
+                for (int a = 0; a < QT; ++a) s[a][c] = mfma16(kf, qf[a][ks], s[a][c]);
+            }
+        }
+
+        // ---- online softmax; lane owns query qrow[a], keys t*64 + c*16 + 4g + r
+        f16x8 pf[QT][2];
+#pragma unroll
+        for (int a = 0; a < QT; ++a) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * KT + c * 16 + g * 4 + r;
+                    float v = s[a][c][r] * p.scale_log2;
+                    const bool masked = (key >= p.Lk) || (p.causal && key > qrow[a]);
+                    v = masked ? -1e30f : v;
+                    s[a][c][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[a], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[a] - m_new);
+            m_run[a] = m_new;
+            float rs = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[a][c][r] - m_new);
+                    s[a][c][r] = e;
+                    rs += e;
+                }
+            l_run[a] = l_run[a] * alpha + rs;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                o[a][dt][0] *= alpha; o[a][dt][1] *= alpha; o[a][dt][2] *= alpha; o[a][dt][3] *= alpha;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f16x8 f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f[r] = (f16)s[a][2 * u][r];
+                    f[4 + r] = (f16)s[a][2 * u + 1][r];
+                }
+                pf[a][u] = f;
+            }
+        }
+
+        // ---- O^T += V^T . P^T ; contraction element e of lane group g is key 32u + 16(e>>2) + 4g + (e&3)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                f16x8 vf;
+                if (TR) {
+                    const f16* a0 = sV + (32 * u + 4 * g + (li >> 2)) * VSTR + dt * 16 + 4 * (li & 3);
+                    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(a0));
+                    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(a0 + 16 * VSTR));
+                    typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
+                    const short8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    vf = __builtin_bit_cast(f16x8, both);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vf[e] = sV[(32 * u + 16 * (e >> 2) + 4 * g + (e & 3)) * VSTR + dt * 16 + li];
+                }
+#pragma unroll
+                for (int a = 0; a < QT; ++a) o[a][dt] = mfma16(vf, pf[a][u], o[a][dt]);
+            }
+        }
+
+        if (has_next) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane holds O[q = qrow][dv = dt*16 + 4g + r]
+#pragma unroll
+    for (int a = 0; a < QT; ++a) {
+        float l = l_run[a];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        if (qrow[a] < p.Lq) {
+            f16* op = p.out + ((size_t)b * p.Lq + qrow[a]) * p.ldo + h * D;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const int dv0 = dt * 16 + g * 4;
+                if (dv0 < D) {
+                    f16x4 hv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hv[r] = (f16)(o[a][dt][r] * inv);
+                    *reinterpret_cast<f16x4*>(op + dv0) = hv;
+                }
+            }
+        }
+    }
+}
+
+template <int D, int QT, bool TR>
+hipError_t attn_launch(const AttnP& p, hipStream_t st) {
+    constexpr int DP = ((D + 31) / 32) * 32;
+    constexpr int DV = ((D + 15) / 16) * 16;
+    constexpr size_t smem = (size_t)2 * 64 * (DP + 8 + odd16(DV)) * sizeof(f16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, QT, TR>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((p.Lq + 64 * QT - 1) / (64 * QT), p.H, p.B);
+    hipLaunchKernelGGL((attn_kernel<D, QT, TR>), grid, dim3(256), smem, st, p);
+    return hipGetLastError();
+}
+
+template <int D>
+hipError_t attn_dispatch(const AttnP& p, bool big, bool tr, hipStream_t st) {
+    if (tr) return big ? attn_launch<D, 2, true>(p, st) : attn_launch<D, 1, true>(p, st);
+    return big ? attn_launch<D, 2, false>(p, st) : attn_launch<D, 1, false>(p, st);
+}
+
+} // namespace
+
+extern "C" int sdod_attention_f16(const void* q, const void* k, const void* v, void* out, int batch, int heads, int lq,
+                                  int lk, int d, int ldq, int ldk, int ldv, int ldo, float scale, int causal,
+                                  void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(q && k && v && out, "null pointer");
+    SDOD_REQUIRE(batch > 0 && heads > 0 && lq > 0 && lk > 0, "bad shape");
+    SDOD_REQUIRE(d == 40 || d == 64 || d == 80 || d == 160, "head dim must be one of 40, 64, 80, 160");
+    SDOD_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "row strides must keep 16-byte alignment");
+    SDOD_REQUIRE(ldq >= heads * d && ldk >= heads * d && ldv >= heads * d && ldo >= heads * d, "row stride < heads*d");
+    SDOD_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)out & 7) == 0, "misaligned pointer");
+    AttnP p{};
+    p.q = (const f16*)q; p.k = (const f16*)k; p.v = (const f16*)v; p.out = (f16*)out;
+    p.B = batch; p.H = heads; p.Lq = lq; p.Lk = lk;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.scale_log2 = scale * 1.4426950408889634f;
+    p.causal = causal;
+    const bool no_tr = std::getenv("SDOD_ATTN_NO_TR") != nullptr; // debugging aid: scalar LDS reads instead of ds_read_b64_tr_b16
+    const bool tr = !no_tr;
+    const bool big = lq >= 2048 && d != 160; // two query tiles per wave once there is enough work to fill the chip
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    switch (d) {
+    case 40: e = attn_dispatch<40>(p, big, tr, st); break;
+    case 64: e = attn_dispatch<64>(p, big, tr, st); break;
+    case 80: e = attn_dispatch<80>(p, big, tr, st); break;
+    default: e = attn_dispatch<160>(p, false, tr, st); break;
+    }
+    SDOD_HIP_CHECK(e);
+    return 0;
+    SDOD_CATCH
+}

@@ -1,0 +1,55 @@
+// common.h -- shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+// Wave = 64 lanes; MFMA 16x16x32 f16 fragments; LDS tiles addressed in 16-byte chunks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define SDOD_DEVICE __device__ __forceinline__
+
+// D[i][j] += sum_k A[i][k] B[k][j];  lane l holds A[l&15][8(l>>4)+e], B[8(l>>4)+e][l&15], e=0..7
+// and D[4(l>>4)+r][l&15], r=0..3   (cdna_hip_programming.md section 3)
+SDOD_DEVICE f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+SDOD_DEVICE f16x8 zero8() {
+    f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return z;
+}
+
+// 16-byte global load / store of 8 halves
+SDOD_DEVICE f16x8 ldg8(const f16* p) { return *reinterpret_cast<const f16x8*>(p); }
+SDOD_DEVICE void stg8(f16* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }
+
+SDOD_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+SDOD_DEVICE float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+SDOD_DEVICE float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_QUICK_GELU = 3 };
+
+SDOD_DEVICE float apply_act(float x, int act) {
+    switch (act) {
+    case ACT_SILU: return silu_f(x);
+    case ACT_GELU: return gelu_erf_f(x);
+    case ACT_QUICK_GELU: return quick_gelu_f(x);
+    default: return x;
+    }
+}
+
+// XCD-aware block remap (bijective form, cdna_hip_programming.md T1): blocks that share the
+// low 3 bits of their id share an XCD/L2; give each XCD a contiguous range of logical tiles.
+SDOD_DEVICE int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

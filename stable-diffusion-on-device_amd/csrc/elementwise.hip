@@ -1,0 +1,407 @@
+// elementwise.hip -- HBM-bound glue kernels of the txt2img path (gfx950).  All fp16 traffic moves as
+// 16-byte lanes (8 halves), grid-stride over <= 2048 workgroups.  The sampler-side kernels restate, on
+// device and with IEEE (non-contracted) fp32 arithmetic, what the reference does on the host:
+//   cfg_combine         context.cpp:359-373 (+ qnn_context.cpp:1065-1081 simple_cast<Accum,Scale>)
+//   dpm_update          dpm_solver.cpp:136-181
+//   timestep_features   context.cpp:257-274
+//   image_to_u8         context.cpp:392-395
+// and the PLMS/DDIM arithmetic of config 1's CPU reference (ldm PLMSSampler; not in /root/reference).
+#include "common.h"
+#include "sdod_hip.h"
+#include "host_util.h"
+
+// The sampler kernels must reproduce the host's fp32 arithmetic bit for bit: hipcc contracts a*b+c into an
+// FMA by default (HIP's __fmul_rn/__fadd_rn are header inlines compiled with contraction allowed, so they do not prevent it).
+#pragma clang fp contract(off)
+
+namespace {
+
+// defined here (under contract(off)) so that no `contract` flag rides along when they are inlined
+SDOD_DEVICE float mul_rn(float a, float b) { return a * b; }
+SDOD_DEVICE float add_rn(float a, float b) { return a + b; }
+SDOD_DEVICE float sub_rn(float a, float b) { return a - b; }
+SDOD_DEVICE float div_rn(float a, float b) { return a / b; }
+
+inline int grid_for(size_t work, int block = 256) {
+    size_t b = (work + block - 1) / block;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+#define GRID_STRIDE(i, n) \
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (size_t)gridDim.x * blockDim.x)
+
+__global__ void geglu_kernel(const f16* x, f16* y, int M, int C) {
+    const int cp = C / 8;
+    const size_t total = (size_t)M * cp;
+    GRID_STRIDE(i, total) {
+        const size_t m = i / cp;
+        const int c0 = (int)(i - m * cp) * 8;
+        const f16x8 a = ldg8(x + m * 2 * C + c0);
+        const f16x8 gt = ldg8(x + m * 2 * C + C + c0);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)((float)a[e] * gelu_erf_f((float)gt[e]));
+        stg8(y + m * C + c0, o);
+    }
+}
+
+__global__ void act_kernel(const f16* x, f16* y, size_t n8, int act) {
+    GRID_STRIDE(i, n8) {
+        const f16x8 a = ldg8(x + i * 8);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)apply_act((float)a[e], act);
+        stg8(y + i * 8, o);
+    }
+}
+
+__global__ void add_kernel(const f16* a, const f16* b, f16* y, size_t n8) {
+    GRID_STRIDE(i, n8) {
+        const f16x8 u = ldg8(a + i * 8), v = ldg8(b + i * 8);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)((float)u[e] + (float)v[e]);
+        stg8(y + i * 8, o);
+    }
+}
+
+__global__ void concat_kernel(const f16* a, const f16* b, f16* y, size_t rows, int c0, int c1) {
+    const int cp = (c0 + c1) / 8, cp0 = c0 / 8;
+    const size_t total = rows * cp;
+    GRID_STRIDE(i, total) {
+        const size_t r = i / cp;
+        const int ch = (int)(i - r * cp);
+        const f16x8 v = ch < cp0 ? ldg8(a + r * c0 + ch * 8) : ldg8(b + r * c1 + (ch - cp0) * 8);
+        stg8(y + r * (c0 + c1) + ch * 8, v);
+    }
+}
+
+// 3x3 pad-1 im2col for tiny Cin (the 4-channel latent): y[row][k], k=(r*3+s)*c+ch, zero-padded to kpad
+__global__ void im2col_small_kernel(const f16* x, f16* y, int n_img, int h, int w, int c, int kpad) {
+    const size_t total = (size_t)n_img * h * w * kpad;
+    GRID_STRIDE(i, total) {
+        const size_t row = i / kpad;
+        const int k = (int)(i - row * kpad);
+        f16 v = (f16)0.f;
+        if (k < 9 * c) {
+            const int tap = k / c, ch = k - tap * c;
+            const int r = tap / 3, s = tap - r * 3;
+            const int img = (int)(row / ((size_t)h * w));
+            const int rem = (int)(row - (size_t)img * h * w);
+            const int oy = rem / w, ox = rem - oy * w;
+            const int yy = oy + r - 1, xx = ox + s - 1;
+            if (yy >= 0 && yy < h && xx >= 0 && xx < w) v = x[(((size_t)img * h + yy) * w + xx) * c + ch];
+        }
+        y[i] = v;
+    }
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* x, f16* y, int n, int c, int hw, float scale) {
+    const size_t total = (size_t)n * c * hw;
+    GRID_STRIDE(i, total) { // i indexes the NHWC output
+        const int ch = (int)(i % c);
+        const size_t t = i / c;
+        const int pix = (int)(t % hw);
+        const int img = (int)(t / hw);
+        y[i] = (f16)(x[((size_t)img * c + ch) * hw + pix] * scale);
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const f16* x, float* y, int n, int c, int hw) {
+    const size_t total = (size_t)n * c * hw;
+    GRID_STRIDE(i, total) { // i indexes the NCHW output
+        const int pix = (int)(i % hw);
+        const size_t t = i / hw;
+        const int ch = (int)(t % c);
+        const int img = (int)(t / c);
+        y[i] = (float)x[((size_t)img * hw + pix) * c + ch];
+    }
+}
+
+__global__ void embedding_kernel(const int32_t* ids, const f16* table, const f16* pos, f16* y, int rows, int seq, int c) {
+    const int cp = c / 8;
+    const size_t total = (size_t)rows * cp;
+    GRID_STRIDE(i, total) {
+        const int row = (int)(i / cp);
+        const int c0 = (int)(i - (size_t)row * cp) * 8;
+        const f16x8 t = ldg8(table + (size_t)ids[row] * c + c0);
+        const f16x8 q = ldg8(pos + (size_t)(row % seq) * c + c0);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)((float)t[e] + (float)q[e]);
+        stg8(y + (size_t)row * c + c0, o);
+    }
+}
+
+__global__ void timestep_features_kernel(const float* t, f16* y, int n, int dim) {
+    const int half = dim / 2;
+    const size_t total = (size_t)n * half;
+    const float log_period = -logf(10000.0f);
+    GRID_STRIDE(i, total) {
+        const int row = (int)(i / half), j = (int)(i - (size_t)row * half);
+        const float arg = t[row] * expf(log_period * j / half);
+        y[(size_t)row * dim + j] = (f16)cosf(arg);
+        y[(size_t)row * dim + half + j] = (f16)sinf(arg);
+    }
+}
+
+// fp16 rows, fp32 math; each thread keeps <= 4 chunks of its row in registers
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* x, f16* y, int M, int N) {
+    __shared__ float red[8];
+    const int row = blockIdx.x;
+    const int cp = N / 8;
+    const f16* xr = x + (size_t)row * N;
+    f16x8 v[4];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = threadIdx.x + 256 * i;
+        if (ch < cp) {
+            v[i] = ldg8(xr + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)v[i][e]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    float ev[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = threadIdx.x + 256 * i;
+        if (ch < cp) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ev[i][e] = __expf((float)v[i][e] - mx);
+                sum += ev[i][e];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    f16* yr = y + (size_t)row * N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = threadIdx.x + 256 * i;
+        if (ch < cp) {
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)(ev[i][e] * inv);
+            stg8(yr + ch * 8, o);
+        }
+    }
+}
+
+// e = g*e_cond + (1-g)*e_uncond   (mode 0, the reference driver: scale, then accumulate)
+// e = e_uncond + g*(e_cond-e_uncond)  (mode 1, ldm's PLMS/DDIM samplers)
+__global__ void cfg_kernel(const f16* eps, float* out, int n, int c, int hw, float g, int uncond_first, int mode) {
+    const size_t total = (size_t)n * c * hw;
+    GRID_STRIDE(i, total) { // NCHW output index
+        const int pix = (int)(i % hw);
+        const size_t t = i / hw;
+        const int ch = (int)(t % c);
+        const int img = (int)(t / c);
+        const int iu = uncond_first ? img : img + n;
+        const int ic = uncond_first ? img + n : img;
+        const float eu = (float)eps[((size_t)iu * hw + pix) * c + ch];
+        const float ec = (float)eps[((size_t)ic * hw + pix) * c + ch];
+        float e;
+        if (mode == 0) {
+            e = mul_rn(ec, g);
+            e = add_rn(e, mul_rn(eu, sub_rn(1.0f, g)));
+        } else {
+            e = add_rn(eu, mul_rn(g, sub_rn(ec, eu)));
+        }
+        out[i] = e;
+    }
+}
+
+// dpm_solver.cpp:136-181, same operation order, no FMA contraction
+__global__ void dpm_update_kernel(float* x, const float* eps, float* y_prev, size_t count, int order, float sigma_s,
+                                  float alpha_s, float sigma_ratio, float c_prev, float c_cur) {
+    GRID_STRIDE(i, count) {
+        const float xv = x[i];
+        const float y = div_rn(add_rn(xv, mul_rn(-sigma_s, eps[i])), alpha_s); // :139
+        float xn = mul_rn(xv, sigma_ratio);                                            // :153 / :168
+        if (order == 2) xn = add_rn(xn, mul_rn(c_prev, y_prev[i]));                 // :169
+        xn = add_rn(xn, mul_rn(c_cur, y));                                          // :154 / :170
+        x[i] = xn;
+        y_prev[i] = y;                                                                    // :177-180
+    }
+}
+
+// ldm DDIM/PLMS step (eta = 0): pred_x0 = (x - s1m_at*e)/s_at ; x = s_aprev*pred_x0 + dir*e
+__global__ void ddim_step_kernel(float* x, const float* e, size_t count, float s1m_at, float s_at, float s_aprev, float dir) {
+    GRID_STRIDE(i, count) {
+        const float ev = e[i];
+        const float x0 = div_rn(sub_rn(x[i], mul_rn(s1m_at, ev)), s_at);
+        x[i] = add_rn(mul_rn(s_aprev, x0), mul_rn(dir, ev));
+    }
+}
+
+__global__ void lincomb4_kernel(float* out, const float* e0, const float* e1, const float* e2, const float* e3, float c0,
+                                float c1, float c2, float c3, float div, size_t count) {
+    GRID_STRIDE(i, count) {
+        float v = mul_rn(c0, e0[i]);
+        if (e1) v = add_rn(v, mul_rn(c1, e1[i]));
+        if (e2) v = add_rn(v, mul_rn(c2, e2[i]));
+        if (e3) v = add_rn(v, mul_rn(c3, e3[i]));
+        out[i] = div_rn(v, div);
+    }
+}
+
+__global__ void to_u8_kernel(const f16* img, uint8_t* out, size_t count, float a, float b, int mode) {
+    GRID_STRIDE(i, count) {
+        float f = add_rn(mul_rn(a, (float)img[i]), b);
+        if (mode == 0) { // context.cpp:392-395: clamp(255*f, 0, 255), truncating cast
+            f = mul_rn(255.0f, f);
+            f = fminf(fmaxf(f, 0.0f), 255.0f);
+        } else {         // ldm txt2img: 255 * clamp(f, 0, 1), truncating cast
+            f = fminf(fmaxf(f, 0.0f), 1.0f);
+            f = mul_rn(255.0f, f);
+        }
+        out[i] = (uint8_t)f;
+    }
+}
+
+} // namespace
+
+#define LAUNCH(kernel, work, st, ...)                                                            \
+    do {                                                                                         \
+        hipLaunchKernelGGL(kernel, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)(st), __VA_ARGS__); \
+        SDOD_HIP_CHECK(hipGetLastError());                                                       \
+    } while (0)
+
+extern "C" int sdod_geglu_f16(const void* x, void* y, int m, int c, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(x && y && m > 0 && c > 0 && c % 8 == 0, "bad argument");
+    LAUNCH(geglu_kernel, (size_t)m * (c / 8), stream, (const f16*)x, (f16*)y, m, c);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_act_f16(const void* x, void* y, size_t n, int act, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(x && y && n > 0 && n % 8 == 0, "bad argument (count must be a multiple of 8)");
+    LAUNCH(act_kernel, n / 8, stream, (const f16*)x, (f16*)y, n / 8, act);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_add_f16(const void* a, const void* b, void* y, size_t n, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(a && b && y && n > 0 && n % 8 == 0, "bad argument (count must be a multiple of 8)");
+    LAUNCH(add_kernel, n / 8, stream, (const f16*)a, (const f16*)b, (f16*)y, n / 8);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_concat_channels_f16(const void* a, const void* b, void* y, size_t rows, int c0, int c1, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(a && b && y && rows > 0 && c0 > 0 && c1 > 0 && c0 % 8 == 0 && c1 % 8 == 0, "bad argument");
+    LAUNCH(concat_kernel, rows * ((c0 + c1) / 8), stream, (const f16*)a, (const f16*)b, (f16*)y, rows, c0, c1);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_im2col3x3_small_f16(const void* x, void* y, int n_img, int h, int w, int c, int kpad, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(x && y && n_img > 0 && h > 0 && w > 0 && c > 0 && kpad >= 9 * c, "bad argument");
+    LAUNCH(im2col_small_kernel, (size_t)n_img * h * w * kpad, stream, (const f16*)x, (f16*)y, n_img, h, w, c, kpad);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_nchw_f32_to_nhwc_f16(const float* x, void* y, int n, int c, int hw, float scale, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(x && y && n > 0 && c > 0 && hw > 0, "bad argument");
+    LAUNCH(nchw_to_nhwc_kernel, (size_t)n * c * hw, stream, x, (f16*)y, n, c, hw, scale);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_nhwc_f16_to_nchw_f32(const void* x, float* y, int n, int c, int hw, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(x && y && n > 0 && c > 0 && hw > 0, "bad argument");
+    LAUNCH(nhwc_to_nchw_kernel, (size_t)n * c * hw, stream, (const f16*)x, y, n, c, hw);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_embedding_f16(const int32_t* ids, const void* table, const void* pos, void* y, int rows, int seq, int c,
+                                  void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(ids && table && pos && y && rows > 0 && seq > 0 && c % 8 == 0, "bad argument");
+    LAUNCH(embedding_kernel, (size_t)rows * (c / 8), stream, ids, (const f16*)table, (const f16*)pos, (f16*)y, rows, seq, c);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_timestep_features_f16(const float* t, void* y, int n, int dim, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(t && y && n > 0 && dim > 0 && dim % 2 == 0, "bad argument");
+    LAUNCH(timestep_features_kernel, (size_t)n * (dim / 2), stream, t, (f16*)y, n, dim);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_softmax_rows_f16(const void* x, void* y, int m, int n, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(x && y && m > 0 && n > 0 && n % 8 == 0 && n <= 8192, "softmax rows need N % 8 == 0 and N <= 8192");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, m, n);
+    SDOD_HIP_CHECK(hipGetLastError());
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_cfg_combine(const void* eps_nhwc, float* e_out, int n, int c, int hw, float guidance, int uncond_first,
+                                int mode, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(eps_nhwc && e_out && n > 0 && c > 0 && hw > 0 && (mode == 0 || mode == 1), "bad argument");
+    LAUNCH(cfg_kernel, (size_t)n * c * hw, stream, (const f16*)eps_nhwc, e_out, n, c, hw, guidance, uncond_first, mode);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_dpm_update(float* x, const float* eps, float* y_prev, size_t count, int order, float sigma_s,
+                               float alpha_s, float sigma_ratio, float c_prev, float c_cur, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(x && eps && y_prev && count > 0 && (order == 1 || order == 2), "bad argument");
+    LAUNCH(dpm_update_kernel, count, stream, x, eps, y_prev, count, order, sigma_s, alpha_s, sigma_ratio, c_prev, c_cur);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_ddim_step_f32(float* x, const float* e, size_t count, float sqrt_one_minus_at, float sqrt_at,
+                                  float sqrt_a_prev, float dir_coef, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(x && e && count > 0, "bad argument");
+    LAUNCH(ddim_step_kernel, count, stream, x, e, count, sqrt_one_minus_at, sqrt_at, sqrt_a_prev, dir_coef);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_lincomb4_f32(float* out, const float* e0, const float* e1, const float* e2, const float* e3, float c0,
+                                 float c1, float c2, float c3, float div, size_t count, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(out && e0 && count > 0 && div != 0.0f, "bad argument");
+    LAUNCH(lincomb4_kernel, count, stream, out, e0, e1, e2, e3, c0, c1, c2, c3, div, count);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_image_to_u8(const void* img, uint8_t* out, size_t count, float a, float b, int mode, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(img && out && count > 0 && (mode == 0 || mode == 1), "bad argument");
+    LAUNCH(to_u8_kernel, count, stream, (const f16*)img, out, count, a, b, mode);
+    return 0;
+    SDOD_CATCH
+}

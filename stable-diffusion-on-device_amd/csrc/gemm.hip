@@ -1,0 +1,472 @@
+// gemm.hip -- fp16 MFMA GEMM with an implicit-im2col A operand (gfx950 / MI355X).
+//
+//   out[M][N] = act(alpha * A[M][K] . W[N][K]^T + bias + row_bias) + residual
+//
+// This is the arithmetic behind every Linear / 1x1 conv / 3x3 conv of the UNet, VAE decoder and CLIP
+// graphs that the reference executes as opaque QNN blobs (qnn_context.cpp:711-713; op inventory in
+// analyze_results.py:20-93).  Design (MI355X-first, not a CUDA tiling):
+//   * one workgroup = 256 threads = 4 wave64; each wave owns a (BM/WM)x(BN/WN) output tile built from
+//     v_mfma_f32_16x16x32_f16 (fp32 accumulate in the unified VGPR/AGPR file);
+//   * K is walked in BK=64 slabs; both operands are K-contiguous, so a slab row is one 128-byte line.
+//     For the 3x3 conv the slab of row m=(img,oy,ox) is the 128-byte channel run of ONE input pixel
+//     (tap (r,s), channels c..c+63) -- im2col never exists in HBM; nearest-2x upsampling, stride 2 and a
+//     two-tensor channel concat are folded into the same address computation;
+//   * slabs are staged global -> registers -> LDS (double-buffered, one barrier per slab; the loads for
+//     slab t+1 are issued before the MFMAs of slab t), LDS rows are XOR-swizzled in 16-byte chunks so
+//     the ds_read_b128 fragment reads are bank-conflict free;
+//   * W is the MFMA "A" operand and the activations the "B" operand, so each lane ends up holding four
+//     CONSECUTIVE output columns of one row: the epilogue packs them to fp16, stages the tile through
+//     LDS and stores full 16-byte row segments (coalesced), with bias / per-image bias (time embedding)
+//     / activation / residual fused;
+//   * workgroup ids are remapped so that the n-tiles of one m-tile share an XCD (its L2 holds the A rows);
+//   * small-M layers (8x8 / 16x16 feature maps) are weight-bandwidth bound: split-K spreads the weight
+//     stream over all 256 CUs, partial slabs are reduced (with the fused epilogue) by a second kernel.
+#include "common.h"
+#include "sdod_hip.h"
+#include "host_util.h"
+
+namespace {
+
+struct GemmP {
+    const f16* a0;
+    const f16* a1;
+    const f16* w;
+    const float* bias;
+    const float* row_bias;
+    const f16* residual;
+    f16* out;
+    float* partial;
+    int M, N, K;
+    int lda, ldw, ldo, ldr;
+    int mode;
+    int h_in, w_in, h_out, w_out, c0, c1, stride, ups;
+    int rows_per_img;
+    int act;
+    float alpha;
+    int bias_on_m;
+    int splits, kt_per_split;
+    int tiles_m, tiles_n;
+};
+
+constexpr int BK = 64;
+
+SDOD_DEVICE int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ (row & 7)) << 3); }
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_IT = BM / 32;
+    constexpr int B_IT = (BN + 31) / 32;
+    constexpr int STAGE = (BM + BN) * 64; // halves per stage
+    constexpr int SC = BN + 8;            // epilogue tile row stride (halves)
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(TM >= 1 && TN >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    f16* smem = reinterpret_cast<f16*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile assignment: consecutive logical ids (same XCD) walk the n-tiles of one m-tile
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int lid = xcd_remap(blockIdx.x, nwg);
+    const int tile_m = lid / p.tiles_n;
+    const int tile_n = lid - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.z;
+
+    const int KT = p.K / BK;
+    int kt_begin = 0, kt_end = KT;
+    if (p.splits > 1) {
+        kt_begin = split * p.kt_per_split;
+        kt_end = min(KT, kt_begin + p.kt_per_split);
+    }
+
+    // ---- per-thread staging geometry: thread owns chunk (tid&7) of rows (tid>>3)+32*i
+    const int ld_chunk = tid & 7;
+    const int ld_row = tid >> 3;
+
+    // A rows: precompute the pixel decomposition for the conv gather
+    int a_img[A_IT], a_oy[A_IT], a_ox[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + ld_row + 32 * i;
+        a_ok[i] = m < p.M;
+        if (p.mode == SDOD_A_CONV3X3) {
+            const int hw = p.h_out * p.w_out;
+            const int mm = a_ok[i] ? m : 0;
+            const int img = mm / hw;
+            const int rem = mm - img * hw;
+            const int oy = rem / p.w_out;
+            a_img[i] = img;
+            a_oy[i] = oy * p.stride;
+            a_ox[i] = (rem - oy * p.w_out) * p.stride;
+        } else {
+            a_img[i] = m;
+            a_oy[i] = 0;
+            a_ox[i] = 0;
+        }
+    }
+    const int cin = p.c0 + p.c1;
+    const int hup = p.h_in << p.ups, wup = p.w_in << p.ups;
+
+    f16x8 ra[A_IT], rb[B_IT];
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        if (p.mode == SDOD_A_CONV3X3) {
+            const int tap = k0 / cin;
+            const int cc = k0 - tap * cin;
+            const int r = tap / 3, s = tap - r * 3;
+            const f16* src = p.a0;
+            int csrc = p.c0, ccs = cc;
+            if (cc >= p.c0) {
+                src = p.a1;
+                csrc = p.c1;
+                ccs = cc - p.c0;
+            }
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                int yy = a_oy[i] + r - 1, xx = a_ox[i] + s - 1;
+                const bool ok = a_ok[i] && yy >= 0 && yy < hup && xx >= 0 && xx < wup;
+                yy >>= p.ups;
+                xx >>= p.ups;
+                const size_t off = ((size_t)(a_img[i] * p.h_in + yy) * p.w_in + xx) * csrc + ccs + ld_chunk * 8;
+                ra[i] = ok ? ldg8(src + off) : zero8();
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const size_t off = (size_t)a_img[i] * p.lda + k0 + ld_chunk * 8;
+                ra[i] = a_ok[i] ? ldg8(p.a0 + off) : zero8();
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int rloc = ld_row + 32 * i;
+            const int n = n0 + rloc;
+            const bool ok = (rloc < BN) && (n < p.N);
+            rb[i] = ok ? ldg8(p.w + (size_t)n * p.ldw + k0 + ld_chunk * 8) : zero8();
+        }
+    };
+
+    auto store_tile = [&](int stage) {
+        f16* sA = smem + stage * STAGE;
+        f16* sB = sA + BM * 64;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int row = ld_row + 32 * i;
+            *reinterpret_cast<f16x8*>(sA + lds_off(row, ld_chunk)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int row = ld_row + 32 * i;
+            if (row < BN) *reinterpret_cast<f16x8*>(sB + lds_off(row, ld_chunk)) = rb[i];
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frag_row = lane & 15;
+    const int frag_chunk = lane >> 4;
+
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        const bool has_next = kt + 1 < kt_end;
+        if (has_next) load_tile(kt + 1);
+
+        const f16* sA = smem + cur * STAGE;
+        const f16* sB = sA + BM * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 xa[TM], wb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                xa[i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WTM + i * 16 + frag_row, ks * 4 + frag_chunk));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                wb[j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(wb[j], xa[i], acc[i][j]);
+        }
+        if (has_next) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  lane holds out[m = .. + (lane&15)][n = .. + 4*(lane>>4) + r], r = 0..3
+    const int e_m = lane & 15;
+    const int e_n = (lane >> 4) * 4;
+
+    if (p.splits > 1) {
+        float* slab = p.partial + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + e_m;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + e_n;
+                if (n + 3 < p.N) {
+                    *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + n) = acc[i][j];
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N) slab[(size_t)m * p.N + n + r] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
+
+    f16* sC = smem; // aliases the staging buffers; all waves are past the final barrier of the K loop
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = wm * WTM + i * 16 + e_m;
+        const int m = m0 + ml;
+        const float* rbias = nullptr;
+        if (p.row_bias != nullptr && m < p.M) rbias = p.row_bias + (size_t)(m / p.rows_per_img) * p.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn * WTN + j * 16 + e_n;
+            const int n = n0 + nl;
+            f16x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[i][j][r] * p.alpha;
+                if (p.bias != nullptr) {
+                    if (p.bias_on_m) {
+                        if (m < p.M) v += p.bias[m];
+                    } else if (n + r < p.N) {
+                        v += p.bias[n + r];
+                    }
+                }
+                if (rbias != nullptr && n + r < p.N) v += rbias[n + r];
+                v = apply_act(v, p.act);
+                h[r] = (f16)v;
+            }
+            *reinterpret_cast<f16x4*>(sC + ml * SC + nl) = h;
+        }
+    }
+    __syncthreads();
+
+    constexpr int CPR = BN / 8; // 16-byte chunks per tile row
+    const bool vec_ok = (p.N % 8 == 0) && (p.ldo % 8 == 0) && (p.residual == nullptr || p.ldr % 8 == 0);
+    for (int idx = tid; idx < BM * CPR; idx += 256) {
+        const int row = idx / CPR;
+        const int ch = idx - row * CPR;
+        const int m = m0 + row, n = n0 + ch * 8;
+        if (m >= p.M || n >= p.N) continue;
+        f16x8 v = *reinterpret_cast<const f16x8*>(sC + row * SC + ch * 8);
+        if (vec_ok) {
+            if (p.residual != nullptr) {
+                const f16x8 rr = ldg8(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)rr[e]);
+            }
+            stg8(p.out + (size_t)m * p.ldo + n, v);
+        } else {
+            for (int e = 0; e < 8; ++e) {
+                if (n + e < p.N) {
+                    float f = (float)v[e];
+                    if (p.residual != nullptr) f += (float)p.residual[(size_t)m * p.ldr + n + e];
+                    p.out[(size_t)m * p.ldo + n + e] = (f16)f;
+                }
+            }
+        }
+    }
+}
+
+// Reduce split-K slabs and apply the fused epilogue.  One thread per 4 consecutive columns.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
+    const int n4 = (p.N + 3) / 4;
+    const size_t total = (size_t)p.M * n4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / n4);
+        const int n = (int)(idx - (size_t)m * n4) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool full = n + 3 < p.N;
+        for (int s = 0; s < p.splits; ++s) {
+            const float* src = p.partial + ((size_t)s * p.M + m) * p.N + n;
+            if (full) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+                v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+            } else {
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.N) v[r] += src[r];
+            }
+        }
+        const float* rbias = p.row_bias ? p.row_bias + (size_t)(m / p.rows_per_img) * p.N : nullptr;
+        for (int r = 0; r < 4; ++r) {
+            if (n + r >= p.N) break;
+            float f = v[r] * p.alpha;
+            if (p.bias) f += p.bias_on_m ? p.bias[m] : p.bias[n + r];
+            if (rbias) f += rbias[n + r];
+            f = apply_act(f, p.act);
+            f = (float)(f16)f; // same rounding point as the un-split path
+            if (p.residual) f += (float)p.residual[(size_t)m * p.ldr + n + r];
+            p.out[(size_t)m * p.ldo + n + r] = (f16)f;
+        }
+    }
+}
+
+struct TileCfg {
+    int bm, bn;
+};
+// id 1..5
+const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {256, 16}, {64, 128}};
+
+template <int BM, int BN, int WM, int WN>
+hipError_t launch_cfg(const GemmP& p, dim3 grid, hipStream_t st) {
+    constexpr size_t smem = (size_t)2 * (BM + BN) * 64 * sizeof(f16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WM, WN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), grid, dim3(256), smem, st, p);
+    return hipGetLastError();
+}
+
+struct Plan {
+    int tile;
+    int splits;
+    int kt_per_split;
+};
+
+Plan make_plan(const sdod_gemm_desc* d) {
+    Plan pl;
+    const int KT = d->K / BK;
+    auto ntiles = [&](int t) { return ((d->M + kTiles[t].bm - 1) / kTiles[t].bm) * ((d->N + kTiles[t].bn - 1) / kTiles[t].bn); };
+    int tile = d->tile;
+    if (tile <= 0 || tile > 5) {
+        if (d->N <= 16) {
+            tile = 4;
+        } else {
+            // largest tile that still gives the 256 CUs at least ~1.5 workgroups each; else the smallest
+            const int target = 384;
+            if (ntiles(1) >= target) tile = 1;
+            else if (ntiles(2) >= target) tile = 2;
+            else tile = 3;
+        }
+    }
+    pl.tile = tile;
+    int splits = d->split_k;
+    if (splits <= 0) {
+        splits = 1;
+        const int nt = ntiles(tile);
+        // weight-bandwidth-bound small-M layers: spread K over idle CUs (keep >= 4 slabs of K per split)
+        if (nt < 192 && KT >= 8 && d->N % 4 == 0) {
+            splits = (512 + nt - 1) / nt;
+            if (splits > KT / 4) splits = KT / 4;
+            if (splits > 32) splits = 32;
+            if (splits < 1) splits = 1;
+        }
+    }
+    if (splits > KT) splits = KT;
+    if (splits < 1) splits = 1;
+    pl.kt_per_split = (KT + splits - 1) / splits;
+    pl.splits = (KT + pl.kt_per_split - 1) / pl.kt_per_split;
+    return pl;
+}
+
+} // namespace
+
+extern "C" size_t sdod_gemm_workspace_bytes(const sdod_gemm_desc* d) {
+    if (!d || d->K <= 0 || d->K % BK) return 0;
+    const Plan pl = make_plan(d);
+    return pl.splits > 1 ? (size_t)pl.splits * d->M * d->N * sizeof(float) : 0;
+}
+
+extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(d != nullptr, "null descriptor");
+    SDOD_REQUIRE(d->a && d->w && d->out, "null operand pointer");
+    SDOD_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "M, N, K must be positive");
+    SDOD_REQUIRE(d->K % BK == 0, "K must be a multiple of 64 (pad the weight / use im2col for Cin<64)");
+    SDOD_REQUIRE(d->ldw >= d->K && d->ldw % 8 == 0, "ldw must be >= K and a multiple of 8");
+    SDOD_REQUIRE(d->ldo >= d->N, "ldo must be >= N");
+    SDOD_REQUIRE(((uintptr_t)d->a & 15) == 0 && ((uintptr_t)d->w & 15) == 0, "operands must be 16-byte aligned");
+    GemmP p{};
+    p.a0 = (const f16*)d->a;
+    p.a1 = (const f16*)d->a2;
+    p.w = (const f16*)d->w;
+    p.bias = (const float*)d->bias;
+    p.row_bias = (const float*)d->row_bias;
+    p.residual = (const f16*)d->residual;
+    p.out = (f16*)d->out;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.lda = d->lda; p.ldw = d->ldw; p.ldo = d->ldo; p.ldr = d->ldr;
+    p.mode = d->a_mode;
+    p.act = d->act;
+    p.alpha = d->alpha;
+    p.bias_on_m = d->bias_on_m;
+    p.rows_per_img = d->rows_per_img > 0 ? d->rows_per_img : 1;
+    if (d->residual) SDOD_REQUIRE(d->ldr >= d->N, "ldr must be >= N");
+    if (d->row_bias) SDOD_REQUIRE(d->rows_per_img > 0 && !d->bias_on_m, "row_bias needs rows_per_img");
+    if (d->a_mode == SDOD_A_CONV3X3) {
+        SDOD_REQUIRE(d->stride == 1 || d->stride == 2, "conv stride must be 1 or 2");
+        SDOD_REQUIRE(d->c0 > 0 && d->c0 % 64 == 0 && d->c1 % 64 == 0, "conv channels must be multiples of 64");
+        SDOD_REQUIRE(d->a2 != nullptr || d->c1 == 0, "c1 > 0 needs a2");
+        SDOD_REQUIRE(d->K == 9 * (d->c0 + d->c1), "conv K must equal 9*(c0+c1)");
+        SDOD_REQUIRE(!(d->upsample && d->stride != 1), "upsample implies stride 1");
+        p.h_in = d->h_in; p.w_in = d->w_in; p.c0 = d->c0; p.c1 = d->c1;
+        p.stride = d->stride; p.ups = d->upsample ? 1 : 0;
+        const int hup = d->h_in << p.ups, wup = d->w_in << p.ups;
+        p.h_out = (hup + 2 - 3) / d->stride + 1;
+        p.w_out = (wup + 2 - 3) / d->stride + 1;
+        SDOD_REQUIRE(d->M == d->n_img * p.h_out * p.w_out, "conv M must equal n_img*h_out*w_out");
+    } else {
+        SDOD_REQUIRE(d->a_mode == SDOD_A_ROWS, "unknown a_mode");
+        SDOD_REQUIRE(d->lda >= d->K && d->lda % 8 == 0, "lda must be >= K and a multiple of 8");
+        p.c0 = d->K; p.c1 = 0; p.h_in = p.w_in = p.h_out = p.w_out = 1; p.stride = 1;
+    }
+    const Plan pl = make_plan(d);
+    p.splits = pl.splits;
+    p.kt_per_split = pl.kt_per_split;
+    if (pl.splits > 1) {
+        SDOD_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= (size_t)pl.splits * d->M * d->N * sizeof(float),
+                     "split-K workspace missing or too small");
+        p.partial = (float*)d->workspace;
+    }
+    const TileCfg tc = kTiles[pl.tile];
+    p.tiles_m = (d->M + tc.bm - 1) / tc.bm;
+    p.tiles_n = (d->N + tc.bn - 1) / tc.bn;
+    dim3 grid(p.tiles_m * p.tiles_n, 1, pl.splits);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    switch (pl.tile) {
+    case 1: e = launch_cfg<128, 128, 2, 2>(p, grid, st); break;
+    case 2: e = launch_cfg<128, 64, 2, 2>(p, grid, st); break;
+    case 3: e = launch_cfg<64, 64, 2, 2>(p, grid, st); break;
+    case 4: e = launch_cfg<256, 16, 4, 1>(p, grid, st); break;
+    default: e = launch_cfg<64, 128, 2, 2>(p, grid, st); break;
+    }
+    SDOD_HIP_CHECK(e);
+    if (pl.splits > 1) {
+        const size_t total = (size_t)d->M * ((d->N + 3) / 4);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+        SDOD_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+    SDOD_CATCH
+}

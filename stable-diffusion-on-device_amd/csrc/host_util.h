@@ -1,0 +1,66 @@
+// host_util.h -- error plumbing of the C ABI: no exception crosses an extern "C" entry point
+// (same convention as the reference's libsdod.cpp:102-108: exception -> status code + message).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <string>
+
+namespace sdod {
+
+enum Status { // mirrors enum libsdod_status_code, csrc/libsdod/api/libsdod.h:11-18
+    OK = 0,
+    INVALID_CONTEXT = 1,
+    INVALID_ARGUMENT = 2,
+    FAILED_ALLOCATION = 3,
+    RUNTIME_ERROR = 4,
+    INTERNAL_ERROR = 5,
+};
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void set_last_error(const std::string& msg);
+const char* get_last_error();
+
+} // namespace sdod
+
+#define SDOD_STR2(x) #x
+#define SDOD_STR(x) SDOD_STR2(x)
+
+#define SDOD_REQUIRE(cond, msg)                                                                                   \
+    do {                                                                                                          \
+        if (!(cond))                                                                                              \
+            throw sdod::Error(sdod::INVALID_ARGUMENT,                                                             \
+                              std::string(__func__) + ": " + (msg) + " [" __FILE__ ":" SDOD_STR(__LINE__) "]");    \
+    } while (0)
+
+#define SDOD_HIP_CHECK(expr)                                                                                      \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess)                                                                                     \
+            throw sdod::Error(sdod::RUNTIME_ERROR, std::string(__func__) + ": HIP error " + hipGetErrorString(_e) + \
+                                                       " [" __FILE__ ":" SDOD_STR(__LINE__) "]");                  \
+    } while (0)
+
+#define SDOD_TRY try {
+#define SDOD_CATCH                                         \
+    }                                                      \
+    catch (const sdod::Error& e) {                         \
+        sdod::set_last_error(e.what());                    \
+        return e.code;                                     \
+    }                                                      \
+    catch (const std::bad_alloc& e) {                      \
+        sdod::set_last_error(e.what());                    \
+        return sdod::FAILED_ALLOCATION;                    \
+    }                                                      \
+    catch (const std::exception& e) {                      \
+        sdod::set_last_error(e.what());                    \
+        return sdod::INTERNAL_ERROR;                       \
+    }                                                      \
+    catch (...) {                                          \
+        sdod::set_last_error("unspecified error");         \
+        return sdod::INTERNAL_ERROR;                       \
+    }

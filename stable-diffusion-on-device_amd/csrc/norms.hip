@@ -1,0 +1,321 @@
+// norms.hip -- GroupNorm(+SiLU) and LayerNorm for NHWC activations on gfx950.
+//
+// GroupNorm is the operator the reference exposes as sdod.EfficientGN / efficient_group_norm
+// (sdod/efficient_gn.py:9-30, :61-70) and declares -- without ever implementing a kernel -- as the
+// custom op `sdod::GroupNorm(in[0], weight, bias; num_groups, eps)` (csrc/sdod_ops/config/group_norm.xml:17-106,
+// group_norm.json:5-21, layout NHWC).  Semantics = torch.nn.functional.group_norm: biased variance over
+// (C/G, spatial) per (n, g), y = (x-mean)/sqrt(var+eps)*w_c+b_c.
+//
+// HBM-bound design: in NHWC a group's data is a strided set of short channel runs, so a block-per-(n,g)
+// kernel would read 20..160-byte fragments.  Instead the statistics pass reads whole pixel rows (fully
+// coalesced 16-byte lanes, many workgroups), every thread owning a fixed 8-channel chunk and keeping
+// per-channel shifted sums in registers; per-group partials go through LDS to a small fp32 scratch.
+// A tiny finalize kernel produces mean/rstd per (n,g); the apply pass is a vectorised elementwise
+// kernel whose per-channel scale/shift live in LDS, with SiLU fused (every ResBlock site) and the
+// channel concat of the UNet skip connections folded into the reads.  Sums are shifted by a per-group
+// pilot value (first element of the group) so E[x^2]-E[x]^2 cancellation stays harmless in fp32.
+// Algorithmic bytes: N*HW*C*sizeof(T) read twice + written once (the second read is L2/MALL resident).
+#include "common.h"
+#include "sdod_hip.h"
+#include "host_util.h"
+
+namespace {
+
+template <typename T>
+struct Chunk8;
+template <>
+struct Chunk8<f16> {
+    static SDOD_DEVICE void load(const f16* p, float (&v)[8]) {
+        const f16x8 h = ldg8(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+    }
+    static SDOD_DEVICE void store(f16* p, const float (&v)[8]) {
+        f16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (f16)v[e];
+        stg8(p, h);
+    }
+};
+template <>
+struct Chunk8<float> {
+    static SDOD_DEVICE void load(const float* p, float (&v)[8]) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+        v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+    static SDOD_DEVICE void store(float* p, const float (&v)[8]) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+};
+
+struct GnP {
+    const void* x0;
+    const void* x1;
+    void* y;
+    const float* w;
+    const float* b;
+    float* partial; // [N][nchunks][G][2]
+    float* stats;   // [N][G][2] mean, rstd
+    int N, HW, C0, C1, C, G, Cg;
+    float eps;
+    int silu;
+    int nchunks, pix_per_chunk;
+    int cpp, npass, pp;
+};
+
+// address of channel c of pixel `pix` of image n in the (possibly concatenated) input
+template <typename T>
+SDOD_DEVICE const T* gn_src(const GnP& p, int n, int pix, int c) {
+    if (c < p.C0) return reinterpret_cast<const T*>(p.x0) + ((size_t)n * p.HW + pix) * p.C0 + c;
+    return reinterpret_cast<const T*>(p.x1) + ((size_t)n * p.HW + pix) * p.C1 + (c - p.C0);
+}
+
+template <typename T, int NPASS>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = reinterpret_cast<float*>(smem_raw); // [pp][C][2]
+    const int n = blockIdx.y;
+    const int chunk_id = blockIdx.x;
+    const int cx = threadIdx.x, py = threadIdx.y;
+    const int pix_begin = chunk_id * p.pix_per_chunk;
+    const int pix_end = min(p.HW, pix_begin + p.pix_per_chunk);
+
+    float s1[NPASS][8], s2[NPASS][8], shift[NPASS][8];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int c0 = (cx + ps * p.cpp) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s1[ps][e] = 0.f;
+            s2[ps][e] = 0.f;
+            const int g = (c0 + e) / p.Cg;
+            shift[ps][e] = (float)*gn_src<T>(p, n, 0, g * p.Cg);
+        }
+    }
+    for (int pix = pix_begin + py; pix < pix_end; pix += p.pp) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int c0 = (cx + ps * p.cpp) * 8;
+            float v[8];
+            Chunk8<T>::load(gn_src<T>(p, n, pix, c0), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[e] - shift[ps][e];
+                s1[ps][e] += d;
+                s2[ps][e] += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int c0 = (cx + ps * p.cpp) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[((size_t)py * p.C + c0 + e) * 2 + 0] = s1[ps][e];
+            red[((size_t)py * p.C + c0 + e) * 2 + 1] = s2[ps][e];
+        }
+    }
+    __syncthreads();
+    const int tid = py * blockDim.x + cx;
+    const int nthreads = blockDim.x * blockDim.y;
+    for (int g = tid; g < p.G; g += nthreads) {
+        float a = 0.f, b = 0.f;
+        for (int q = 0; q < p.pp; ++q)
+            for (int c = g * p.Cg; c < (g + 1) * p.Cg; ++c) {
+                a += red[((size_t)q * p.C + c) * 2 + 0];
+                b += red[((size_t)q * p.C + c) * 2 + 1];
+            }
+        float* dst = p.partial + (((size_t)n * p.nchunks + chunk_id) * p.G + g) * 2;
+        dst[0] = a;
+        dst[1] = b;
+    }
+}
+
+template <typename T>
+__global__ void gn_finalize_kernel(const GnP p) {
+    const int n = blockIdx.x;
+    for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int ch = 0; ch < p.nchunks; ++ch) {
+            const float* src = p.partial + (((size_t)n * p.nchunks + ch) * p.G + g) * 2;
+            a += src[0];
+            b += src[1];
+        }
+        const float cnt = (float)p.HW * (float)p.Cg;
+        const float shift = (float)*gn_src<T>(p, n, 0, g * p.Cg);
+        const float md = a / cnt;
+        float var = b / cnt - md * md;
+        var = var < 0.f ? 0.f : var;
+        p.stats[((size_t)n * p.G + g) * 2 + 0] = shift + md;
+        p.stats[((size_t)n * p.G + g) * 2 + 1] = 1.0f / sqrtf(var + p.eps);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sc = reinterpret_cast<float*>(smem_raw); // [C] scale
+    float* sh = sc + p.C;                            // [C] shift
+    const int n = blockIdx.y;
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+        const int g = c / p.Cg;
+        const float mean = p.stats[((size_t)n * p.G + g) * 2 + 0];
+        const float rstd = p.stats[((size_t)n * p.G + g) * 2 + 1];
+        const float w = p.w ? p.w[c] : 1.0f;
+        const float b = p.b ? p.b[c] : 0.0f;
+        sc[c] = rstd * w;
+        sh[c] = b - mean * rstd * w;
+    }
+    __syncthreads();
+    const int cp = p.C / 8;
+    const size_t total = (size_t)p.HW * cp;
+    T* yout = reinterpret_cast<T*>(p.y) + (size_t)n * p.HW * p.C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int pix = (int)(i / cp);
+        const int c0 = (int)(i - (size_t)pix * cp) * 8;
+        float v[8];
+        Chunk8<T>::load(gn_src<T>(p, n, pix, c0), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = v[e] * sc[c0 + e] + sh[c0 + e];
+            if (p.silu) f = silu_f(f);
+            v[e] = f;
+        }
+        Chunk8<T>::store(yout + (size_t)pix * p.C + c0, v);
+    }
+}
+
+template <typename T>
+void gn_launch(GnP& p, hipStream_t st) {
+    const int cp = p.C / 8;
+    p.npass = (cp + 255) / 256;
+    SDOD_REQUIRE(p.npass <= 2 && cp % p.npass == 0, "unsupported channel count for GroupNorm");
+    p.cpp = cp / p.npass;
+    p.pp = 256 / p.cpp;
+    if (p.pp < 1) p.pp = 1;
+    if (p.pp > p.pix_per_chunk) p.pp = p.pix_per_chunk;
+    const size_t smem_stats = (size_t)p.pp * p.C * 2 * sizeof(float);
+    dim3 sgrid(p.nchunks, p.N), sblock(p.cpp, p.pp);
+    if (p.npass == 1)
+        hipLaunchKernelGGL((gn_stats_kernel<T, 1>), sgrid, sblock, smem_stats, st, p);
+    else
+        hipLaunchKernelGGL((gn_stats_kernel<T, 2>), sgrid, sblock, smem_stats, st, p);
+    SDOD_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(p.N), dim3(64), 0, st, p);
+    SDOD_HIP_CHECK(hipGetLastError());
+    const size_t total = (size_t)p.HW * cp;
+    int bx = (int)((total + 255) / 256);
+    const int cap = 2048 / (p.N > 0 ? p.N : 1) + 1;
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(bx, p.N), dim3(256), (size_t)p.C * 2 * sizeof(float), st, p);
+    SDOD_HIP_CHECK(hipGetLastError());
+}
+
+constexpr int GN_MAX_CHUNKS = 128;
+
+// ---------------------------------------------------------------- LayerNorm: one wave per row
+__global__ __launch_bounds__(256) void layer_norm_kernel(const f16* x, f16* y, const float* w, const float* b, int M,
+                                                         int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int cp = C / 8;
+    const f16* xr = x + (size_t)row * C;
+    f16x8 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < cp) {
+            v[i] = ldg8(xr + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)v[i][e];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < cp) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = (float)v[i][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+    f16* yr = y + (size_t)row * C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < cp) {
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = ch * 8 + e;
+                const float ww = w ? w[c] : 1.0f, bb = b ? b[c] : 0.0f;
+                o[e] = (f16)(((float)v[i][e] - mean) * rstd * ww + bb);
+            }
+            stg8(yr + ch * 8, o);
+        }
+    }
+}
+
+} // namespace
+
+extern "C" size_t sdod_group_norm_workspace_bytes(int n, int groups) {
+    if (n <= 0 || groups <= 0) return 0;
+    return ((size_t)n * GN_MAX_CHUNKS * groups * 2 + (size_t)n * groups * 2) * sizeof(float);
+}
+
+extern "C" int sdod_group_norm_nhwc(const void* x, const void* x2, void* y, const float* weight, const float* bias, int n,
+                                    int hw, int c0, int c1, int groups, float eps, int silu, int dtype, void* workspace,
+                                    void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(x && y && workspace, "null pointer");
+    SDOD_REQUIRE(n > 0 && hw > 0 && c0 > 0 && c1 >= 0 && groups > 0, "bad shape");
+    SDOD_REQUIRE(c1 == 0 || x2 != nullptr, "c1 > 0 needs x2");
+    const int c = c0 + c1;
+    SDOD_REQUIRE(c % groups == 0, "num_channels must be divisible by num_groups");
+    SDOD_REQUIRE(c0 % 8 == 0 && c1 % 8 == 0, "channel counts must be multiples of 8");
+    SDOD_REQUIRE((weight == nullptr) == (bias == nullptr), "weight and bias must both be given or both be null");
+    SDOD_REQUIRE(dtype == SDOD_F16 || dtype == SDOD_F32, "dtype must be SDOD_F16 or SDOD_F32");
+    GnP p{};
+    p.x0 = x; p.x1 = x2; p.y = y; p.w = weight; p.b = bias;
+    p.N = n; p.HW = hw; p.C0 = c0; p.C1 = c1; p.C = c; p.G = groups; p.Cg = c / groups;
+    p.eps = eps; p.silu = silu;
+    // enough statistics workgroups to cover the chip, bounded scratch
+    int nchunks = (512 + n - 1) / n;
+    if (nchunks > GN_MAX_CHUNKS) nchunks = GN_MAX_CHUNKS;
+    if (nchunks > hw) nchunks = hw;
+    p.pix_per_chunk = (hw + nchunks - 1) / nchunks;
+    p.nchunks = (hw + p.pix_per_chunk - 1) / p.pix_per_chunk;
+    p.partial = (float*)workspace;
+    p.stats = p.partial + (size_t)n * GN_MAX_CHUNKS * groups * 2;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SDOD_F16) gn_launch<f16>(p, st);
+    else gn_launch<float>(p, st);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_layer_norm_f16(const void* x, void* y, const float* weight, const float* bias, int m, int c, float eps,
+                                   void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(x && y, "null pointer");
+    SDOD_REQUIRE(m > 0 && c > 0 && c % 8 == 0 && c <= 2048, "LayerNorm needs C % 8 == 0 and C <= 2048");
+    hipLaunchKernelGGL(layer_norm_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y,
+                       weight, bias, m, c, eps);
+    SDOD_HIP_CHECK(hipGetLastError());
+    return 0;
+    SDOD_CATCH
+}

@@ -1,0 +1,103 @@
+"""ctypes loader for the in-tree HIP libraries.  Fails loudly: there is no CPU fallback."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib'))
+
+_cache = {}
+
+
+def load(name):
+    """Return the CDLL for lib/<name>; raises ImportError with build instructions if missing."""
+    if name in _cache:
+        return _cache[name]
+    path = os.path.join(LIB_DIR, name)
+    if not os.path.exists(path):
+        raise ImportError(
+            f'{path} not found: build the MI355X extension first '
+            f'(python -c "import __graft_entry__ as g; g.build()" or make -C stable-diffusion-on-device_amd). '
+            f'There is no CPU fallback for the HIP path.')
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    _cache[name] = lib
+    return lib
+
+
+class SdodError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f'[libsdod status {code}] {msg}')
+        self.code = code
+
+
+def hip():
+    lib = load('libsdod_hip.so')
+    if not getattr(lib, '_sdod_typed', False):
+        _declare(lib)
+        lib._sdod_typed = True
+    return lib
+
+
+c_void_p, c_int, c_float, c_size_t, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_char_p
+
+
+class GemmDesc(ctypes.Structure):
+    """mirror of `struct sdod_gemm_desc` (include/sdod_hip.h)"""
+    _fields_ = [
+        ('a', c_void_p), ('a2', c_void_p), ('w', c_void_p), ('bias', c_void_p), ('row_bias', c_void_p),
+        ('residual', c_void_p), ('out', c_void_p), ('workspace', c_void_p), ('workspace_bytes', c_size_t),
+        ('M', c_int), ('N', c_int), ('K', c_int),
+        ('lda', c_int), ('ldw', c_int), ('ldo', c_int), ('ldr', c_int),
+        ('a_mode', c_int),
+        ('n_img', c_int), ('h_in', c_int), ('w_in', c_int), ('c0', c_int), ('c1', c_int),
+        ('stride', c_int), ('upsample', c_int), ('rows_per_img', c_int),
+        ('act', c_int), ('alpha', c_float), ('bias_on_m', c_int), ('split_k', c_int), ('tile', c_int),
+    ]
+
+
+def _declare(lib):
+    P = c_void_p
+    sig = {
+        'sdod_gemm_f16': (c_int, [ctypes.POINTER(GemmDesc), P]),
+        'sdod_gemm_workspace_bytes': (c_size_t, [ctypes.POINTER(GemmDesc)]),
+        'sdod_group_norm_workspace_bytes': (c_size_t, [c_int, c_int]),
+        'sdod_group_norm_nhwc': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, P, P]),
+        'sdod_layer_norm_f16': (c_int, [P, P, P, P, c_int, c_int, c_float, P]),
+        'sdod_attention_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+        'sdod_softmax_rows_f16': (c_int, [P, P, c_int, c_int, P]),
+        'sdod_geglu_f16': (c_int, [P, P, c_int, c_int, P]),
+        'sdod_act_f16': (c_int, [P, P, c_size_t, c_int, P]),
+        'sdod_add_f16': (c_int, [P, P, P, c_size_t, P]),
+        'sdod_concat_channels_f16': (c_int, [P, P, P, c_size_t, c_int, c_int, P]),
+        'sdod_im2col3x3_small_f16': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+        'sdod_nchw_f32_to_nhwc_f16': (c_int, [P, P, c_int, c_int, c_int, c_float, P]),
+        'sdod_nhwc_f16_to_nchw_f32': (c_int, [P, P, c_int, c_int, c_int, P]),
+        'sdod_embedding_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+        'sdod_timestep_features_f16': (c_int, [P, P, c_int, c_int, P]),
+        'sdod_cfg_combine': (c_int, [P, P, c_int, c_int, c_int, c_float, c_int, c_int, P]),
+        'sdod_dpm_update': (c_int, [P, P, P, c_size_t, c_int, c_float, c_float, c_float, c_float, c_float, P]),
+        'sdod_ddim_step_f32': (c_int, [P, P, c_size_t, c_float, c_float, c_float, c_float, P]),
+        'sdod_lincomb4_f32': (c_int, [P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_size_t, P]),
+        'sdod_image_to_u8': (c_int, [P, P, c_size_t, c_float, c_float, c_int, P]),
+        'sdod_hip_last_error': (c_char_p, []),
+        'sdod_hip_device_info': (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_size_t), c_char_p, c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
+HIP_SYMBOLS = [
+    'sdod_gemm_f16', 'sdod_gemm_workspace_bytes', 'sdod_group_norm_workspace_bytes', 'sdod_group_norm_nhwc',
+    'sdod_layer_norm_f16', 'sdod_attention_f16', 'sdod_softmax_rows_f16', 'sdod_geglu_f16', 'sdod_act_f16',
+    'sdod_add_f16', 'sdod_concat_channels_f16', 'sdod_im2col3x3_small_f16', 'sdod_nchw_f32_to_nhwc_f16',
+    'sdod_nhwc_f16_to_nchw_f32', 'sdod_embedding_f16', 'sdod_timestep_features_f16', 'sdod_cfg_combine',
+    'sdod_dpm_update', 'sdod_ddim_step_f32', 'sdod_lincomb4_f32', 'sdod_image_to_u8', 'sdod_hip_last_error',
+    'sdod_hip_device_info',
+]
+
+
+def check(code):
+    if code != 0:
+        msg = hip().sdod_hip_last_error()
+        raise SdodError(code, msg.decode() if msg else 'unknown error')

@@ -1,0 +1,313 @@
+"""Thin torch-tensor wrappers over the kernel-level C ABI (include/sdod_hip.h).
+
+torch supplies device memory and the current stream only; every computation below is a call into
+lib/libsdod_hip.so.  Activations are NHWC fp16; a torch NCHW tensor in channels_last memory format
+IS that layout, so the conversions are views."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+ACT = {None: 0, 'none': 0, 'silu': 1, 'gelu': 2, 'quick_gelu': 3}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _req(t, dtype=None, name='tensor'):
+    if not t.is_cuda:
+        raise ValueError(f'{name} must live on the GPU')
+    if not t.is_contiguous():
+        raise ValueError(f'{name} must be contiguous')
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f'{name} must be {dtype}, got {t.dtype}')
+    return t
+
+
+_ws = {}
+
+
+def workspace(nbytes, device, tag='default'):
+    """Grow-only fp32 scratch per (device, tag); reused across calls on the same stream."""
+    key = (device, tag)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((max(nbytes, 1) + 3) // 4, dtype=torch.float32, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=None, alpha=1.0, out=None,
+         conv=None, a2=None, bias_on_m=False, split_k=0, tile=0):
+    """out = act(alpha * A @ W^T + bias + row_bias) + residual.
+
+    a: fp16 [M, K] (rows mode) or NHWC [N, H, W, C0] with conv=dict(stride=1|2, upsample=bool) (3x3 pad 1);
+    a2: optional second NHWC source concatenated on channels; w: fp16 [Nout, K] (conv: K = 9*(C0+C1), KRSC)."""
+    lib = _lib.hip()
+    _req(a, torch.float16, 'a'); _req(w, torch.float16, 'w')
+    d = GemmDesc()
+    nout, k = w.shape
+    if conv is None:
+        m = a.shape[0]
+        assert a.shape[1] == k, (a.shape, w.shape)
+        d.a_mode = 0
+        d.lda = k
+        out_shape = (m, nout)
+    else:
+        n_img, h, wd, c0 = a.shape
+        c1 = 0
+        if a2 is not None:
+            _req(a2, torch.float16, 'a2')
+            assert a2.shape[:3] == a.shape[:3]
+            c1 = a2.shape[3]
+        stride = int(conv.get('stride', 1)); ups = 1 if conv.get('upsample', False) else 0
+        hup, wup = h << ups, wd << ups
+        ho, wo = (hup + 2 - 3) // stride + 1, (wup + 2 - 3) // stride + 1
+        m = n_img * ho * wo
+        d.a_mode = 1
+        d.n_img, d.h_in, d.w_in, d.c0, d.c1 = n_img, h, wd, c0, c1
+        d.stride, d.upsample = stride, ups
+        d.a2 = _p(a2)
+        out_shape = (n_img, ho, wo, nout)
+    if out is None:
+        out = torch.empty(out_shape, dtype=torch.float16, device=a.device)
+    else:
+        _req(out, torch.float16, 'out')
+        assert out.numel() == m * nout
+    d.a, d.w, d.out = _p(a), _p(w), _p(out)
+    d.M, d.N, d.K = m, nout, k
+    d.ldw, d.ldo = k, nout
+    if bias is not None:
+        _req(bias, torch.float32, 'bias'); d.bias = _p(bias)
+    if row_bias is not None:
+        _req(row_bias, torch.float32, 'row_bias'); d.row_bias = _p(row_bias); d.rows_per_img = rows_per_img
+    if residual is not None:
+        _req(residual, torch.float16, 'residual'); assert residual.numel() == m * nout
+        d.residual = _p(residual); d.ldr = nout
+    d.act = ACT[act]
+    d.alpha = alpha
+    d.bias_on_m = 1 if bias_on_m else 0
+    d.split_k = split_k
+    d.tile = tile
+    need = lib.sdod_gemm_workspace_bytes(ctypes.byref(d))
+    if need:
+        ws = workspace(need, a.device, 'gemm')
+        d.workspace = _p(ws); d.workspace_bytes = ws.numel() * 4
+    check(lib.sdod_gemm_f16(ctypes.byref(d), _stream()))
+    return out
+
+
+def group_norm_nhwc(x, groups, weight=None, bias=None, eps=1e-5, silu=False, x2=None, out=None):
+    """x: [N, ..., C] channels-last fp16/fp32 (optionally concatenated with x2 on C)."""
+    lib = _lib.hip()
+    _req(x, None, 'x')
+    assert x.dtype in (torch.float16, torch.float32)
+    n, c0 = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c0)
+    c1 = 0
+    if x2 is not None:
+        _req(x2, x.dtype, 'x2'); c1 = x2.shape[-1]
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (c0 + c1,), dtype=x.dtype, device=x.device)
+    if weight is not None:
+        weight = weight.detach().to(torch.float32).contiguous(); bias = bias.detach().to(torch.float32).contiguous()
+    ws = workspace(lib.sdod_group_norm_workspace_bytes(n, groups), x.device, 'gn')
+    check(lib.sdod_group_norm_nhwc(_p(x), _p(x2), _p(out), _p(weight), _p(bias), n, hw, c0, c1, groups, eps,
+                                   1 if silu else 0, 0 if x.dtype == torch.float16 else 1, _p(ws), _stream()))
+    return out
+
+
+def group_norm_nchw(x, groups, weight=None, bias=None, eps=1e-5, silu=False):
+    """torch-semantics entry used by sdod.EfficientGN: x is [N, C, *]; returns a tensor of the same logical
+    shape (channels_last strides).  The permute to NHWC is a view when x is already channels_last."""
+    if x.dtype not in (torch.float16, torch.float32):
+        raise TypeError('EfficientGN HIP kernel supports float16 and float32')
+    n, c = x.shape[0], x.shape[1]
+    xl = x.detach().reshape(n, c, -1).permute(0, 2, 1).contiguous()  # [N, S, C]
+    y = group_norm_nhwc(xl, groups, weight, bias, eps, silu)
+    return y.permute(0, 2, 1).reshape(x.shape)
+
+
+def layer_norm(x, weight, bias, eps=1e-5, out=None):
+    lib = _lib.hip()
+    _req(x, torch.float16, 'x')
+    c = x.shape[-1]; m = x.numel() // c
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.sdod_layer_norm_f16(_p(x), _p(out), _p(weight), _p(bias), m, c, eps, _stream()))
+    return out
+
+
+def attention(q, k, v, heads, scale=None, causal=False, out=None):
+    """q: [B, Lq, heads*d], k/v: [B, Lk, heads*d] fp16 (row strides = last-dim size)."""
+    lib = _lib.hip()
+    for t, nme in ((q, 'q'), (k, 'k'), (v, 'v')):
+        _req(t, torch.float16, nme)
+    b, lq, c = q.shape
+    lk = k.shape[1]
+    d = c // heads
+    if scale is None:
+        scale = d ** -0.5
+    if out is None:
+        out = torch.empty_like(q)
+    check(lib.sdod_attention_f16(_p(q), _p(k), _p(v), _p(out), b, heads, lq, lk, d, q.shape[2], k.shape[2], v.shape[2],
+                                 out.shape[2], scale, 1 if causal else 0, _stream()))
+    return out
+
+
+def attention_strided(q, k, v, out, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo, scale, causal=False):
+    """raw form for packed qkv buffers: pointers may be column offsets into wider rows"""
+    lib = _lib.hip()
+    check(lib.sdod_attention_f16(q, k, v, out, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo, scale, 1 if causal else 0,
+                                 _stream()))
+
+
+def softmax_rows(x, out=None):
+    lib = _lib.hip()
+    _req(x, torch.float16, 'x')
+    n = x.shape[-1]; m = x.numel() // n
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.sdod_softmax_rows_f16(_p(x), _p(out), m, n, _stream()))
+    return out
+
+
+def geglu(x, out=None):
+    lib = _lib.hip()
+    _req(x, torch.float16, 'x')
+    c = x.shape[-1] // 2; m = x.numel() // (2 * c)
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (c,), dtype=torch.float16, device=x.device)
+    check(lib.sdod_geglu_f16(_p(x), _p(out), m, c, _stream()))
+    return out
+
+
+def activation(x, act, out=None):
+    lib = _lib.hip()
+    _req(x, torch.float16, 'x')
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.sdod_act_f16(_p(x), _p(out), x.numel(), ACT[act], _stream()))
+    return out
+
+
+def add(a, b, out=None):
+    lib = _lib.hip()
+    _req(a, torch.float16, 'a'); _req(b, torch.float16, 'b')
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.sdod_add_f16(_p(a), _p(b), _p(out), a.numel(), _stream()))
+    return out
+
+
+def concat_channels(a, b):
+    lib = _lib.hip()
+    _req(a, torch.float16, 'a'); _req(b, torch.float16, 'b')
+    c0, c1 = a.shape[-1], b.shape[-1]
+    rows = a.numel() // c0
+    out = torch.empty(a.shape[:-1] + (c0 + c1,), dtype=torch.float16, device=a.device)
+    check(lib.sdod_concat_channels_f16(_p(a), _p(b), _p(out), rows, c0, c1, _stream()))
+    return out
+
+
+def im2col3x3_small(x, kpad=64):
+    lib = _lib.hip()
+    _req(x, torch.float16, 'x')
+    n, h, w, c = x.shape
+    out = torch.empty((n * h * w, kpad), dtype=torch.float16, device=x.device)
+    check(lib.sdod_im2col3x3_small_f16(_p(x), _p(out), n, h, w, c, kpad, _stream()))
+    return out
+
+
+def nchw_f32_to_nhwc_f16(x, scale=1.0):
+    lib = _lib.hip()
+    _req(x, torch.float32, 'x')
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    out = torch.empty((n,) + tuple(x.shape[2:]) + (c,), dtype=torch.float16, device=x.device)
+    check(lib.sdod_nchw_f32_to_nhwc_f16(_p(x), _p(out), n, c, hw, scale, _stream()))
+    return out
+
+
+def nhwc_f16_to_nchw_f32(x):
+    lib = _lib.hip()
+    _req(x, torch.float16, 'x')
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    out = torch.empty((n, c) + tuple(x.shape[1:-1]), dtype=torch.float32, device=x.device)
+    check(lib.sdod_nhwc_f16_to_nchw_f32(_p(x), _p(out), n, c, hw, _stream()))
+    return out
+
+
+def embedding(ids, table, pos):
+    lib = _lib.hip()
+    _req(ids, torch.int32, 'ids'); _req(table, torch.float16, 'table'); _req(pos, torch.float16, 'pos')
+    rows = ids.numel(); seq = pos.shape[0]; c = table.shape[1]
+    out = torch.empty(tuple(ids.shape) + (c,), dtype=torch.float16, device=ids.device)
+    check(lib.sdod_embedding_f16(_p(ids), _p(table), _p(pos), _p(out), rows, seq, c, _stream()))
+    return out
+
+
+def timestep_features(t, dim=320):
+    lib = _lib.hip()
+    _req(t, torch.float32, 't')
+    out = torch.empty((t.numel(), dim), dtype=torch.float16, device=t.device)
+    check(lib.sdod_timestep_features_f16(_p(t), _p(out), t.numel(), dim, _stream()))
+    return out
+
+
+def cfg_combine(eps_nhwc, guidance, uncond_first=True, mode=1):
+    lib = _lib.hip()
+    _req(eps_nhwc, torch.float16, 'eps')
+    n2, c = eps_nhwc.shape[0], eps_nhwc.shape[-1]
+    n = n2 // 2
+    spatial = tuple(eps_nhwc.shape[1:-1])
+    hw = eps_nhwc.numel() // (n2 * c)
+    out = torch.empty((n, c) + spatial, dtype=torch.float32, device=eps_nhwc.device)
+    check(lib.sdod_cfg_combine(_p(eps_nhwc), _p(out), n, c, hw, guidance, 1 if uncond_first else 0, mode, _stream()))
+    return out
+
+
+def dpm_update(x, eps, y_prev, order, sigma_s, alpha_s, sigma_ratio, c_prev, c_cur):
+    lib = _lib.hip()
+    for t in (x, eps, y_prev):
+        _req(t, torch.float32)
+    check(lib.sdod_dpm_update(_p(x), _p(eps), _p(y_prev), x.numel(), order, sigma_s, alpha_s, sigma_ratio, c_prev, c_cur,
+                              _stream()))
+
+
+def ddim_step(x, e, sqrt_one_minus_at, sqrt_at, sqrt_a_prev, dir_coef):
+    lib = _lib.hip()
+    _req(x, torch.float32); _req(e, torch.float32)
+    check(lib.sdod_ddim_step_f32(_p(x), _p(e), x.numel(), sqrt_one_minus_at, sqrt_at, sqrt_a_prev, dir_coef, _stream()))
+
+
+def lincomb4(es, coefs, div):
+    lib = _lib.hip()
+    es = list(es) + [None] * (4 - len(es)); coefs = list(coefs) + [0.0] * (4 - len(coefs))
+    out = torch.empty_like(es[0])
+    check(lib.sdod_lincomb4_f32(_p(out), _p(es[0]), _p(es[1]), _p(es[2]), _p(es[3]), coefs[0], coefs[1], coefs[2], coefs[3],
+                                div, out.numel(), _stream()))
+    return out
+
+
+def image_to_u8(img_nhwc, a=0.5, b=0.5, mode=1):
+    lib = _lib.hip()
+    _req(img_nhwc, torch.float16, 'img')
+    out = torch.empty(img_nhwc.shape, dtype=torch.uint8, device=img_nhwc.device)
+    check(lib.sdod_image_to_u8(_p(img_nhwc), _p(out), img_nhwc.numel(), a, b, mode, _stream()))
+    return out
+
+
+def device_info():
+    lib = _lib.hip()
+    cu = ctypes.c_int(); mem = ctypes.c_size_t(); arch = ctypes.create_string_buffer(64)
+    check(lib.sdod_hip_device_info(ctypes.byref(cu), ctypes.byref(mem), arch, 64))
+    return {'cu_count': cu.value, 'hbm_bytes': mem.value, 'arch': arch.value.decode()}

@@ -1,0 +1,117 @@
+"""GroupNorm operator of the `sdod` package (reference: sdod/efficient_gn.py:9-90).
+
+Public surface kept: EfficientGNFun, efficient_group_norm, EfficientGN(num_groups, num_channels,
+eps=1e-5, affine=True, device=None, dtype=None, impl=None), impl in {None, 'eff', 'ln', 'bn'},
+parameters `weight`/`bias` (state-dict compatible with nn.GroupNorm) and the ONNX symbols
+`sdod::GroupNorm` / `sdod::ParameterlessGroupNorm` with attributes num_groups_i, eps_f.
+
+What differs, on purpose:
+  * impl='eff' on a CUDA(ROCm) tensor runs the hand-written gfx950 GroupNorm kernel
+    (csrc/norms.hip through the C ABI sdod_group_norm_nhwc), the kernel the reference declares in
+    csrc/sdod_ops/config/group_norm.{xml,json} but never ships.  If the HIP library is missing this
+    raises -- there is no silent fallback on a GPU tensor.  CPU tensors (ONNX export, CPU tests) use
+    F.group_norm exactly as the reference's forward does (:11-12).
+  * impl='ln'/'bn' apply the affine parameters (reference quirk Q1, :84-85 has it commented out, so
+    its own tests/gn_to_ln.py prints False for them); with identity affine the results are identical.
+  * `fuse_silu=True` (extra, default False) fuses the SiLU that follows every ResBlock GroupNorm.
+"""
+from functools import reduce
+import operator as op
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _hip_group_norm(x, num_groups, weight, bias, eps, silu=False):
+    from .amd import ops  # raises loudly if lib/libsdod_hip.so is not built
+    return ops.group_norm_nchw(x, num_groups, weight, bias, eps, silu)
+
+
+class EfficientGNFun(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, num_groups, weight=None, bias=None, eps=1e-5):
+        if input.is_cuda:
+            return _hip_group_norm(input, num_groups, weight, bias, eps)
+        return F.group_norm(input, num_groups, weight, bias, eps)
+
+    @staticmethod
+    def symbolic(g, input, num_groups, weight, bias, eps):
+        from torch.onnx import symbolic_helper as sh
+        num_groups = sh._maybe_get_const(num_groups, 'i')
+        eps = sh._maybe_get_const(eps, 'f')
+        no_weight = weight is None or sh._is_none(weight)
+        no_bias = bias is None or sh._is_none(bias)
+        if no_weight:
+            assert no_bias, 'bias without weight'
+            ret = g.op('sdod::ParameterlessGroupNorm', input, num_groups_i=num_groups, eps_f=eps)
+        else:
+            assert not no_bias, 'weight without bias'
+            ret = g.op('sdod::GroupNorm', input, weight, bias, num_groups_i=num_groups, eps_f=eps)
+        ret.setType(input.type())
+        return ret
+
+
+def efficient_group_norm(input, num_groups, weight=None, bias=None, eps=1e-5):
+    return EfficientGNFun.apply(input, num_groups, weight, bias, eps)
+
+
+class EfficientGN(nn.Module):
+    def __init__(self, num_groups: int, num_channels: int, eps: float = 1e-5, affine: bool = True, device=None,
+                 dtype=None, impl=None, fuse_silu: bool = False) -> None:
+        super().__init__()
+        if num_channels % num_groups != 0:
+            raise ValueError('num_channels must be divisible by num_groups')
+        if impl not in [None, 'eff', 'ln', 'bn']:
+            raise ValueError('EfficientGN impl parameter should be one of None, "eff", "ln" or "bn"')
+        self.num_groups = num_groups
+        self.num_channels = num_channels
+        self.eps = eps
+        self.affine = affine
+        self.impl = impl
+        self.fuse_silu = fuse_silu
+        if affine:
+            self.weight = nn.Parameter(torch.empty(num_channels, device=device, dtype=dtype))
+            self.bias = nn.Parameter(torch.empty(num_channels, device=device, dtype=dtype))
+        else:
+            self.register_parameter('weight', None)
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        if self.affine:
+            nn.init.ones_(self.weight)
+            nn.init.zeros_(self.bias)
+
+    def _affine(self, y):
+        if not self.affine:
+            return y
+        bshape = (1, self.num_channels) + (1,) * (y.dim() - 2)
+        return y * self.weight.reshape(bshape) + self.bias.reshape(bshape)
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        shape = input.shape
+        assert shape[1] == self.num_channels
+        cpg = self.num_channels // self.num_groups
+        spatial = reduce(op.mul, shape[2:], 1)
+
+        if self.impl == 'eff':
+            if input.is_cuda and self.fuse_silu:
+                return _hip_group_norm(input, self.num_groups, self.weight, self.bias, self.eps, silu=True)
+            out = efficient_group_norm(input, self.num_groups, self.weight, self.bias, self.eps)
+        elif self.impl is None:
+            out = F.group_norm(input, self.num_groups, self.weight, self.bias, self.eps)
+        elif self.impl == 'ln':
+            y = input.reshape(shape[0], self.num_groups, cpg * spatial)
+            y = F.layer_norm(y, (cpg * spatial,), None, None, eps=self.eps)
+            out = self._affine(y.reshape(shape))
+        elif self.impl == 'bn':
+            y = input.reshape(1, shape[0] * self.num_groups, cpg * spatial)
+            y = F.batch_norm(y, None, None, None, None, training=True, momentum=0.0, eps=self.eps)
+            out = self._affine(y.reshape(shape))
+        else:
+            raise NotImplementedError(self.impl)
+        return F.silu(out) if self.fuse_silu else out
+
+    def extra_repr(self) -> str:
+        return '{num_groups}, {num_channels}, eps={eps}, affine={affine}'.format(**self.__dict__)

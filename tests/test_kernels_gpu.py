@@ -1,0 +1,339 @@
+"""GPU parity tests of the individual gfx950 kernels, called through the C ABI (lib/libsdod_hip.so).
+
+Checker: plain PyTorch fp32 on the CPU of the same op on the same fp16-rounded inputs.
+Tolerances (stated, fp16 in/out with fp32 accumulation): rel-L2 <= 2e-3 per kernel,
+max-abs <= 2e-2 * max|ref|; integer / exact paths are compared bit-for-bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return torch.device('cuda:0')
+
+
+def rel_l2(a, b):
+    a = a.double().flatten(); b = b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def check(out, ref, tol=2e-3, name=''):
+    out = out.detach().float().cpu(); ref = ref.detach().float().cpu()
+    assert out.shape == ref.shape, (name, out.shape, ref.shape)
+    assert torch.isfinite(out).all(), f'{name}: non-finite output'
+    r = rel_l2(out, ref)
+    mx = float((out - ref).abs().max()); scale = float(ref.abs().max())
+    assert r <= tol, f'{name}: rel-L2 {r:.3e} > {tol} (max abs {mx:.3e}, ref max {scale:.3e})'
+    assert mx <= 2e-2 * scale + 1e-3, f'{name}: max abs {mx:.3e} vs ref max {scale:.3e}'
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).half()
+
+
+def test_library_and_device():
+    from sdod.amd import ops
+    info = ops.device_info()
+    assert info['arch'].startswith('gfx950'), info
+    assert info['cu_count'] == 256
+
+
+# ------------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('m,n,k,tile', [
+    (256, 128, 64, 1), (256, 128, 128, 2), (200, 72, 192, 3), (512, 16, 128, 4), (100, 136, 64, 5),
+    (8192, 320, 320, 0), (333, 320, 640, 0), (128, 1280, 1280, 0), (77 * 2, 768, 768, 0), (4096, 4, 64, 0),
+    (1000, 3, 1152, 0),
+])
+def test_gemm_rows(m, n, k, tile):
+    from sdod.amd import ops
+    a = rnd((m, k), 1); w = rnd((n, k), 2, k ** -0.5)
+    bias = torch.randn(n, generator=torch.Generator().manual_seed(3))
+    res = rnd((m, n), 4)
+    ref = F.silu(1.25 * (a.float() @ w.float().t()) + bias).half().float() + res.float()
+    d = dev()
+    out = ops.gemm(a.to(d), w.to(d), bias.to(d), residual=res.to(d), act='silu', alpha=1.25, tile=tile)
+    torch.cuda.synchronize()
+    check(out, ref, name=f'gemm {m}x{n}x{k} tile{tile}')
+
+
+@pytest.mark.parametrize('split', [2, 5, 16])
+def test_gemm_split_k(split):
+    from sdod.amd import ops
+    m, n, k = 128, 320, 2880
+    a = rnd((m, k), 5); w = rnd((n, k), 6, k ** -0.5)
+    bias = torch.randn(n, generator=torch.Generator().manual_seed(7))
+    rb = torch.randn(2, n, generator=torch.Generator().manual_seed(8))
+    ref = a.float() @ w.float().t() + bias + rb.repeat_interleave(64, 0)
+    d = dev()
+    out = ops.gemm(a.to(d), w.to(d), bias.to(d), row_bias=rb.to(d), rows_per_img=64, split_k=split)
+    check(out, ref, name=f'splitk {split}')
+
+
+def test_gemm_bias_on_m_and_gelu():
+    from sdod.amd import ops
+    m, n, k = 512, 256, 512
+    a = rnd((m, k), 9); w = rnd((n, k), 10, k ** -0.5)
+    bias = torch.randn(m, generator=torch.Generator().manual_seed(11))
+    d = dev()
+    out = ops.gemm(a.to(d), w.to(d), bias.to(d), bias_on_m=True, act='gelu')
+    check(out, F.gelu(a.float() @ w.float().t() + bias[:, None]), name='bias_on_m gelu')
+    out = ops.gemm(a.to(d), w.to(d), None, act='quick_gelu')
+    x = a.float() @ w.float().t()
+    check(out, x * torch.sigmoid(1.702 * x), name='quick_gelu')
+
+
+def conv_ref(x_nhwc, w_krsc, bias, stride=1, upsample=False):
+    x = x_nhwc.float().permute(0, 3, 1, 2)
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode='nearest')
+    cout = w_krsc.shape[0]
+    w = w_krsc.float().reshape(cout, 3, 3, -1).permute(0, 3, 1, 2)
+    y = F.conv2d(x, w, bias, stride=stride, padding=1)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,stride,ups', [
+    (2, 16, 16, 64, 128, 1, False), (1, 9, 7, 128, 64, 1, False), (2, 16, 16, 64, 64, 2, False),
+    (1, 8, 8, 128, 128, 1, True), (2, 64, 64, 320, 320, 1, False), (2, 8, 8, 1280, 1280, 1, False),
+    (1, 7, 7, 64, 64, 2, False),
+])
+def test_conv3x3(n, h, w, cin, cout, stride, ups):
+    from sdod.amd import ops
+    x = rnd((n, h, w, cin), 20); wt = rnd((cout, 9 * cin), 21, (9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(22))
+    ref = conv_ref(x, wt, bias, stride, ups)
+    d = dev()
+    out = ops.gemm(x.to(d), wt.to(d), bias.to(d), conv=dict(stride=stride, upsample=ups))
+    check(out, ref, name=f'conv {n}x{h}x{w} {cin}->{cout} s{stride} u{ups}')
+
+
+def test_conv3x3_concat_rowbias_residual():
+    from sdod.amd import ops
+    n, h, w, c0, c1, cout = 2, 16, 16, 128, 64, 192
+    x0 = rnd((n, h, w, c0), 30); x1 = rnd((n, h, w, c1), 31)
+    wt = rnd((cout, 9 * (c0 + c1)), 32, (9 * (c0 + c1)) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(33))
+    rb = torch.randn(n, cout, generator=torch.Generator().manual_seed(34))
+    res = rnd((n, h, w, cout), 35)
+    ref = conv_ref(torch.cat([x0, x1], -1), wt, bias) + rb[:, None, None, :]
+    ref = ref.half().float() + res.float()
+    d = dev()
+    out = ops.gemm(x0.to(d), wt.to(d), bias.to(d), a2=x1.to(d), conv=dict(stride=1), row_bias=rb.to(d), rows_per_img=h * w,
+                   residual=res.to(d))
+    check(out, ref, name='conv concat')
+
+
+def test_conv_small_cin_via_im2col():
+    from sdod.amd import ops
+    n, h, w, cin, cout = 2, 64, 64, 4, 320
+    x = rnd((n, h, w, cin), 40); wt = rnd((cout, 9 * cin), 41, (9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(42))
+    ref = conv_ref(x, wt, bias)
+    d = dev()
+    wpad = torch.zeros(cout, 64, dtype=torch.float16); wpad[:, :36] = wt
+    cols = ops.im2col3x3_small(x.to(d), 64)
+    out = ops.gemm(cols, wpad.to(d), bias.to(d)).reshape(n, h, w, cout)
+    check(out, ref, name='conv cin=4')
+
+
+# -------------------------------------------------------------------------------------------- GroupNorm
+@pytest.mark.parametrize('n,hw,c,g,dtype,silu', [
+    (2, 4096, 320, 32, torch.float16, True), (2, 64, 2560, 32, torch.float16, True), (1, 16384, 128, 32, torch.float16, False),
+    (2, 1024, 960, 32, torch.float16, True), (1, 100, 64, 32, torch.float32, False), (3, 7, 8, 2, torch.float32, True),
+    (2, 256, 1920, 32, torch.float16, False),
+])
+def test_group_norm(n, hw, c, g, dtype, silu):
+    from sdod.amd import ops
+    gen = torch.Generator().manual_seed(50)
+    x = (torch.randn(n, hw, c, generator=gen) * 2 + 3).to(dtype)   # non-zero mean exercises the shifted sums
+    wt = 1 + 0.1 * torch.randn(c, generator=gen); b = 0.1 * torch.randn(c, generator=gen)
+    eps = 1e-6
+    ref = F.group_norm(x.float().permute(0, 2, 1), g, wt, b, eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    d = dev()
+    out = ops.group_norm_nhwc(x.to(d), g, wt.to(d), b.to(d), eps, silu)
+    check(out, ref, tol=2e-3 if dtype == torch.float16 else 2e-5, name=f'gn {n}x{hw}x{c}')
+
+
+def test_group_norm_concat_sources():
+    from sdod.amd import ops
+    gen = torch.Generator().manual_seed(51)
+    n, hw, c0, c1 = 2, 256, 1280, 640   # 1920/32 = 60 channels per group: groups straddle the concat boundary
+    x0 = torch.randn(n, hw, c0, generator=gen).half(); x1 = (torch.randn(n, hw, c1, generator=gen) * 3 - 1).half()
+    wt = 1 + 0.1 * torch.randn(c0 + c1, generator=gen); b = 0.1 * torch.randn(c0 + c1, generator=gen)
+    ref = F.silu(F.group_norm(torch.cat([x0, x1], -1).float().permute(0, 2, 1), 32, wt, b, 1e-5).permute(0, 2, 1))
+    d = dev()
+    out = ops.group_norm_nhwc(x0.to(d), 32, wt.to(d), b.to(d), 1e-5, True, x2=x1.to(d))
+    check(out, ref, name='gn concat')
+
+
+def test_efficient_gn_module_matches_reference_golden(golden_dir):
+    """sdod.EfficientGN(impl='eff') on the GPU vs outputs of the reference's own module (tests/golden/gn_efficient.npz,
+    generated by oracle/gen_golden.py from /root/reference/sdod/efficient_gn.py)."""
+    import sdod
+    g = np.load(os.path.join(golden_dir, 'gn_efficient.npz'))
+    d = dev()
+    for ci in range(5):
+        x = torch.from_numpy(g[f'c{ci}_x']); w = torch.from_numpy(g[f'c{ci}_w']); b = torch.from_numpy(g[f'c{ci}_b'])
+        groups = int(g[f'c{ci}_groups'])
+        for eps in (1e-5, 1e-6):
+            m = sdod.EfficientGN(groups, x.shape[1], eps=eps, impl='eff').to(d)
+            with torch.no_grad():
+                m.weight.copy_(w); m.bias.copy_(b)
+                y = m(x.to(d))
+            ref = torch.from_numpy(g[f'c{ci}_eff_{eps:g}'])
+            assert y.shape == ref.shape
+            check(y, ref, tol=2e-5, name=f'EfficientGN eff c{ci} eps{eps:g}')
+        m = sdod.EfficientGN(groups, x.shape[1], affine=False, impl='eff').to(d)
+        with torch.no_grad():
+            check(m(x.to(d)), torch.from_numpy(g[f'c{ci}_eff_noaffine']), tol=2e-5, name=f'EfficientGN noaffine c{ci}')
+
+
+def test_layer_norm():
+    from sdod.amd import ops
+    for m, c in ((8192, 320), (2048, 640), (512, 1280), (154, 768)):
+        gen = torch.Generator().manual_seed(60)
+        x = (torch.randn(m, c, generator=gen) + 0.5).half()
+        wt = 1 + 0.1 * torch.randn(c, generator=gen); b = 0.1 * torch.randn(c, generator=gen)
+        d = dev()
+        out = ops.layer_norm(x.to(d), wt.to(d), b.to(d), 1e-5)
+        check(out, F.layer_norm(x.float(), (c,), wt, b, 1e-5), name=f'ln {m}x{c}')
+
+
+# -------------------------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, heads, causal=False):
+    b, lq, c = q.shape
+    d = c // heads
+    qh = q.float().reshape(b, lq, heads, d).transpose(1, 2)
+    kh = k.float().reshape(b, -1, heads, d).transpose(1, 2)
+    vh = v.float().reshape(b, -1, heads, d).transpose(1, 2)
+    o = F.scaled_dot_product_attention(qh, kh, vh, is_causal=causal)
+    return o.transpose(1, 2).reshape(b, lq, c)
+
+
+@pytest.mark.parametrize('b,heads,lq,lk,d,causal', [
+    (1, 2, 128, 128, 40, False), (2, 8, 4096, 4096, 40, False), (2, 8, 1024, 1024, 80, False),
+    (2, 8, 256, 256, 160, False), (2, 8, 64, 64, 160, False), (2, 8, 4096, 77, 40, False),
+    (2, 8, 1024, 77, 80, False), (2, 8, 256, 77, 160, False), (2, 12, 77, 77, 64, True), (1, 3, 200, 333, 64, False),
+    (1, 2, 100, 100, 80, True),
+])
+@pytest.mark.parametrize('use_tr', [True, False])
+def test_attention(b, heads, lq, lk, d, causal, use_tr):
+    from sdod.amd import ops
+    if not use_tr and lq * lk > 1024 * 1024:
+        pytest.skip('scalar-LDS fallback only checked on small cases')
+    q = rnd((b, lq, heads * d), 70); k = rnd((b, lk, heads * d), 71); v = rnd((b, lk, heads * d), 72)
+    ref = attn_ref(q, k, v, heads, causal)
+    dv = dev()
+    if use_tr:
+        os.environ.pop('SDOD_ATTN_NO_TR', None)
+    else:
+        os.environ['SDOD_ATTN_NO_TR'] = '1'
+    try:
+        out = ops.attention(q.to(dv), k.to(dv), v.to(dv), heads, causal=causal)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop('SDOD_ATTN_NO_TR', None)
+    check(out, ref, tol=3e-3, name=f'attn b{b} h{heads} {lq}x{lk} d{d} causal{causal} tr{use_tr}')
+
+
+def test_attention_peaked_rows_force_rescale():
+    """One key dominates late in the sequence: the running max jumps at a chosen tile (online-softmax rescale path)."""
+    from sdod.amd import ops
+    b, heads, l, d = 1, 2, 512, 40
+    q = rnd((b, l, heads * d), 73); k = rnd((b, l, heads * d), 74); v = rnd((b, l, heads * d), 75)
+    k[:, 300] = q[:, 17] * 6.0
+    k[:, 450] = q[:, 200] * 9.0
+    ref = attn_ref(q, k, v, heads)
+    dv = dev()
+    check(ops.attention(q.to(dv), k.to(dv), v.to(dv), heads), ref, tol=3e-3, name='attn peaked')
+
+
+# ------------------------------------------------------------------------------------------ elementwise
+def test_elementwise_and_layout():
+    from sdod.amd import ops
+    d = dev()
+    x = rnd((300, 2 * 640), 80)
+    check(ops.geglu(x.to(d)), x[:, :640].float() * F.gelu(x[:, 640:].float()), name='geglu')
+    a = rnd((4096, 8), 81); bb = rnd((4096, 8), 82)
+    check(ops.add(a.to(d), bb.to(d)), a.float() + bb.float(), name='add')
+    check(ops.activation(a.to(d), 'silu'), F.silu(a.float()), name='silu')
+    c0 = rnd((50, 128), 83); c1 = rnd((50, 64), 84)
+    assert torch.equal(ops.concat_channels(c0.to(d), c1.to(d)).cpu(), torch.cat([c0, c1], -1))
+    z = torch.randn(2, 4, 64, 64, generator=torch.Generator().manual_seed(85))
+    nhwc = ops.nchw_f32_to_nhwc_f16(z.to(d), 1.0 / 0.18215)
+    assert torch.equal(nhwc.cpu(), (z * np.float32(1.0 / 0.18215)).permute(0, 2, 3, 1).half())
+    back = ops.nhwc_f16_to_nchw_f32(nhwc)
+    assert torch.equal(back.cpu(), nhwc.cpu().float().permute(0, 3, 1, 2))
+    s = rnd((64, 4096), 86, 3.0)
+    check(ops.softmax_rows(s.to(d)), torch.softmax(s.float(), -1), name='softmax')
+    ids = torch.randint(0, 1000, (2, 77), generator=torch.Generator().manual_seed(87), dtype=torch.int32)
+    table = rnd((1000, 768), 88); pos = rnd((77, 768), 89)
+    check(ops.embedding(ids.to(d), table.to(d), pos.to(d)), table[ids.long()].float() + pos.float()[None], name='embedding')
+
+
+def test_timestep_features_vs_oracle(oracle_lib):
+    """context.cpp:257-274 restated in oracle/sdod_oracle.c; the GPU writes fp16, so compare after rounding."""
+    from sdod.amd import ops
+    ts = np.array([999.0, 949.05, 499.5, 49.949936, 1.0, 0.0], np.float32)
+    ref = np.zeros((len(ts), 320), np.float32)
+    for i, t in enumerate(ts):
+        oracle_lib.oracle_timestep_features(float(t), 320, ref[i].ctypes.data)
+    out = ops.timestep_features(torch.from_numpy(ts).to(dev()), 320).float().cpu().numpy()
+    assert np.abs(out - ref).max() <= 2e-3, np.abs(out - ref).max()   # fp16 rounding of values in [-1, 1] plus device sin/cos
+
+
+def test_sampler_kernels_bit_exact_vs_oracle(oracle_lib, golden_dir):
+    """CFG combine + DPM-Solver++ update on the GPU reproduce the reference's host arithmetic bit for bit
+    (trajectory from tests/golden/dpm_steps20.json, generated by the reference's own dpm_solver.cpp)."""
+    import json
+    from sdod.amd import ops
+    g = json.load(open(os.path.join(golden_dir, 'dpm_steps20.json')))
+    f = lambda key: np.array(g[key], np.uint32).view(np.float32)
+    sig, alp, phi, i2r = f('sigmas_bits'), f('alphas_bits'), f('phis_bits'), f('i2rs_bits')
+    d = dev()
+    x = torch.from_numpy(f('x0_bits').copy()).to(d)
+    yprev = torch.zeros_like(x)
+    for s, rec in enumerate(g['trajectory']):
+        eps = torch.from_numpy(np.array(rec['eps_bits'], np.uint32).view(np.float32).copy()).to(d)
+        order = 1 if s == 0 else 2
+        ratio = np.float32(sig[s + 1] / sig[s])
+        if order == 1:
+            c_prev = np.float32(0); c_cur = np.float32(-alp[s + 1] * phi[s + 1])
+        else:
+            c_prev = np.float32(np.float32(alp[s + 1] * phi[s + 1]) * i2r[s + 1])
+            c_cur = np.float32(np.float32(-alp[s + 1] * phi[s + 1]) * np.float32(np.float32(1) + i2r[s + 1]))
+        ops.dpm_update(x, eps, yprev, order, float(sig[s]), float(alp[s]), float(ratio), float(c_prev), float(c_cur))
+        got = x.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, np.array(rec['x_bits'], np.uint32)), f'step {s}'
+    # CFG, reference form (mode 0) vs oracle_cfg_combine
+    rng = np.random.default_rng(3)
+    eps16 = torch.from_numpy(rng.standard_normal((2, 64, 4)).astype(np.float16))   # [2n=2][hw][c]
+    out = ops.cfg_combine(eps16.to(d), 7.5, uncond_first=False, mode=0).cpu().numpy()
+    ec = eps16[0].float().numpy().T.copy(); eu = eps16[1].float().numpy().T.copy()
+    ref = np.zeros_like(ec)
+    oracle_lib.oracle_cfg_combine(ref.ctypes.data, ec.ctypes.data, eu.ctypes.data, 7.5, ec.size)
+    assert np.array_equal(out.reshape(-1).view(np.uint32), ref.reshape(-1).view(np.uint32))
+
+
+def test_image_to_u8_vs_oracle(oracle_lib):
+    from sdod.amd import ops
+    rng = np.random.default_rng(4)
+    img = (rng.standard_normal((1, 32, 32, 3)) * 0.8).astype(np.float16)
+    d = dev()
+    got = ops.image_to_u8(torch.from_numpy(img).to(d), a=1.0, b=0.0, mode=0).cpu().numpy()
+    f32 = img.astype(np.float32).reshape(-1)
+    ref = np.zeros(f32.size, np.uint8)
+    oracle_lib.oracle_to_uint8(ref.ctypes.data, f32.ctypes.data, f32.size)
+    assert np.array_equal(got.reshape(-1), ref)
+    got = ops.image_to_u8(torch.from_numpy(img).to(d), a=0.5, b=0.5, mode=1).cpu().numpy()
+    ref = (255.0 * np.clip((f32 + np.float32(1.0)) / np.float32(2.0), 0, 1)).astype(np.uint8)
+    assert np.array_equal(got.reshape(-1), ref)
