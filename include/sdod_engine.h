@@ -1,0 +1,82 @@
+/*
+ * sdod_engine.h -- graph-level C ABI of the MI355X txt2img engine.
+ *
+ * A "graph" here plays the role the serialized QNN graphs play in the reference: the reference's
+ * Context loads four graphs -- "unet.serialized", "text_encoder.serialized", "vae_decoder.serialized",
+ * "temb" (csrc/libsdod/src/context.cpp:105) -- allocates their I/O tensors (context.cpp:201-218) and
+ * calls QnnGraph::execute() on them (qnn_context.cpp:711-713).  Here each graph is a static launch list
+ * of the hand-written gfx950 kernels of include/sdod_hip.h over a weight arena and an activation arena
+ * in HBM, optionally replayed as one hipGraph.
+ *
+ * I/O slots (device memory owned by the graph; sdod_graph_io() returns pointer + size):
+ *   UNET          in0 x    fp32 NCHW [B][4][H][W]        (context.cpp:214  x = unet.allocate_input(0))
+ *                 in1 temb fp16 [B][4*model_ch]          (context.cpp:215  t = unet.allocate_input(1))
+ *                 in2 ctx  fp16 [B][77][ctx_dim]         (context.cpp:216  p_cond / p_uncond = input(2))
+ *                 out0 e   fp16 NHWC [B][H][W][4]        (context.cpp:218  e = unet.allocate_output(0))
+ *   TEMB          in0 t    fp32 [B]                      (model time, dpm_solver.cpp:115)
+ *                 out0     fp16 [B][4*model_ch]          (context.cpp:257-278: sinusoid + temb graph)
+ *   TEXT_ENCODER  in0 ids  int32 [B][77]                 (context.cpp:207 tokens)
+ *                 out0     fp16 [B][77][ctx_dim]         (context.cpp:208 p)
+ *   VAE_DECODER   in0 z    fp32 NCHW [B][4][H][W]        (context.cpp:220 y)
+ *                 out0 img fp16 NHWC [B][8H][8W][3] in [-1,1]  (context.cpp:221 img)
+ *
+ * Parameters are addressed by their CompVis-ldm / HF-CLIP state-dict names (without the
+ * `model.diffusion_model.` / `first_stage_model.` / `cond_stage_model.transformer.` prefixes) and are
+ * given in their canonical PyTorch layouts (conv [Cout][Cin][kh][kw], linear [out][in]); the engine
+ * repacks them to KRSC fp16 in HBM.  All functions return 0 or a libsdod status code; the message is
+ * available from sdod_hip_last_error().
+ */
+#ifndef SDOD_ENGINE_H
+#define SDOD_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifndef SDOD_API
+#define SDOD_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum sdod_graph_kind { SDOD_GRAPH_UNET = 0, SDOD_GRAPH_VAE_DECODER = 1, SDOD_GRAPH_TEXT_ENCODER = 2, SDOD_GRAPH_TEMB = 3 };
+
+typedef struct sdod_model_config {
+    int latent_channels; /* 4 */
+    int latent_h;        /* 64 (SD1.x 512px), 96 (SD2.1 768px) */
+    int latent_w;
+    int model_channels;  /* 320 */
+    int context_dim;     /* 768 (SD1.x), 1024 (SD2.x) */
+    int context_len;     /* 77 */
+    int num_heads;       /* 8 (SD1.x: head dim = C/8); 0 = use head_dim */
+    int head_dim;        /* 64 (SD2.x); ignored when num_heads > 0 */
+    int vocab_size;      /* 49408 */
+    int text_layers;     /* 12 */
+    int text_heads;      /* 12 */
+    int vae_channels;    /* 128 */
+} sdod_model_config;
+
+SDOD_API void sdod_model_config_sd14(sdod_model_config* cfg);
+
+SDOD_API int sdod_graph_create(void** graph, int kind, const sdod_model_config* cfg, int batch);
+SDOD_API int sdod_graph_destroy(void* graph);
+
+/* parameter table (fixed by kind + config) */
+SDOD_API int sdod_graph_num_params(void* graph);
+SDOD_API int sdod_graph_param_info(void* graph, int index, const char** name, int* ndim, int64_t shape[4]);
+/* data: host pointer in canonical layout, dtype SDOD_F32 or SDOD_F16 (include/sdod_hip.h), numel from shape */
+SDOD_API int sdod_graph_set_param(void* graph, const char* name, const void* data, int dtype, const int64_t* shape, int ndim);
+/* load every parameter from a .sdodw container (see DESIGN.md "weight file"); prefix is prepended to graph names */
+SDOD_API int sdod_graph_load_file(void* graph, const char* path, const char* prefix);
+/* checks that every parameter is set, sizes and allocates the activation arena, builds the launch list */
+SDOD_API int sdod_graph_finalize(void* graph);
+SDOD_API int sdod_graph_io(void* graph, int is_output, int index, void** device_ptr, size_t* bytes);
+/* run once on `stream`.  use_hip_graph != 0: the launch list is captured on first use and replayed */
+SDOD_API int sdod_graph_execute(void* graph, void* stream, int use_hip_graph);
+SDOD_API int sdod_graph_stats(void* graph, size_t* weight_bytes, size_t* arena_bytes, int* num_launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDOD_ENGINE_H */

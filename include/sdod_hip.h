@@ -37,7 +37,7 @@ extern "C" {
 
 enum sdod_act { SDOD_ACT_NONE = 0, SDOD_ACT_SILU = 1, SDOD_ACT_GELU = 2, SDOD_ACT_QUICK_GELU = 3 };
 enum sdod_dtype { SDOD_F16 = 0, SDOD_F32 = 1 };
-enum sdod_a_mode { SDOD_A_ROWS = 0, SDOD_A_CONV3X3 = 1 };
+enum sdod_a_mode { SDOD_A_ROWS = 0, SDOD_A_CONV3X3 = 1 /* NHWC gather: 3x3 pad 1 or 1x1 */ };
 
 /* out[M][N] = act(alpha * A[M][K] . W[N][K]^T + bias + row_bias) + residual        (fp16 in/out, fp32 acc)
  * A is either a row-major matrix (SDOD_A_ROWS) or gathered on the fly from an NHWC image for a 3x3
@@ -48,7 +48,7 @@ typedef struct sdod_gemm_desc {
     const void* a2;       /* conv only: second concat source [n_img][h_in][w_in][c1], or NULL */
     const void* w;        /* fp16 [N][ldw] */
     const void* bias;     /* fp32 [N] (or [M] if bias_on_m), may be NULL */
-    const void* row_bias; /* fp32 [M / rows_per_img][N] added per image, may be NULL */
+    const void* row_bias; /* fp16 [M / rows_per_img][ld_row_bias] added per image (time embedding), may be NULL */
     const void* residual; /* fp16 [M][ldr], may be NULL */
     void* out;            /* fp16 [M][ldo] */
     void* workspace;      /* fp32 split-K slabs, >= split_k*M*N*4 bytes when split_k > 1 */
@@ -59,7 +59,9 @@ typedef struct sdod_gemm_desc {
     int n_img, h_in, w_in, c0, c1; /* conv geometry: input (pre-upsample) */
     int stride;                    /* conv: 1 or 2 */
     int upsample;                  /* conv: 1 = nearest 2x before the conv */
+    int ksize;                     /* conv: 3 (default when 0) or 1 */
     int rows_per_img;              /* for row_bias */
+    int ld_row_bias;               /* row stride of row_bias (0 = N) */
     int act;
     float alpha;
     int bias_on_m;
@@ -99,6 +101,10 @@ SDOD_API int sdod_add_f16(const void* a, const void* b, void* y, size_t n, void*
 SDOD_API int sdod_concat_channels_f16(const void* a, const void* b, void* y, size_t rows, int c0, int c1, void* stream);
 SDOD_API int sdod_im2col3x3_small_f16(const void* x, void* y, int n_img, int h, int w, int c, int kpad, void* stream);
 SDOD_API int sdod_nchw_f32_to_nhwc_f16(const float* x, void* y, int n, int c, int hw, float scale, void* stream);
+/* y(NHWC fp16)[img][pix][o] = sum_c w[o][c]*(scale*x(NCHW fp32)[img][c][pix]) + b[o]; w/b fp32 [c][c]/[c] or NULL
+ * (identity).  Folds ldm's z/0.18215 and first_stage_model.post_quant_conv into the layout change. */
+SDOD_API int sdod_latent_prep_f16(const float* x, const float* w, const float* b, void* y, int n, int c, int hw,
+                                  float scale, void* stream);
 SDOD_API int sdod_nhwc_f16_to_nchw_f32(const void* x, float* y, int n, int c, int hw, void* stream);
 SDOD_API int sdod_embedding_f16(const int32_t* ids, const void* table, const void* pos, void* y, int rows, int seq,
                                 int c, void* stream);

@@ -109,6 +109,25 @@ __global__ void nchw_to_nhwc_kernel(const float* x, f16* y, int n, int c, int hw
     }
 }
 
+// y[img][pix][o] = sum_c w[o][c] * (scale * x[img][c][pix]) + b[o]   (tiny channel counts: the 4-channel latent).
+// Folds ldm's `z / 0.18215` and the VAE's 1x1 post_quant_conv into the layout change.
+__global__ void latent_prep_kernel(const float* x, const float* w, const float* b, f16* y, int n, int c, int hw, float scale) {
+    const size_t total = (size_t)n * c * hw;
+    GRID_STRIDE(i, total) { // i indexes the NHWC output
+        const int o = (int)(i % c);
+        const size_t t = i / c;
+        const int pix = (int)(t % hw);
+        const int img = (int)(t / hw);
+        float acc = b ? b[o] : 0.f;
+        if (w) {
+            for (int ch = 0; ch < c; ++ch) acc += w[o * c + ch] * (x[((size_t)img * c + ch) * hw + pix] * scale);
+        } else {
+            acc += x[((size_t)img * c + o) * hw + pix] * scale;
+        }
+        y[i] = (f16)acc;
+    }
+}
+
 __global__ void nhwc_to_nchw_kernel(const f16* x, float* y, int n, int c, int hw) {
     const size_t total = (size_t)n * c * hw;
     GRID_STRIDE(i, total) { // i indexes the NCHW output
@@ -324,6 +343,15 @@ extern "C" int sdod_nchw_f32_to_nhwc_f16(const float* x, void* y, int n, int c, 
     SDOD_TRY
     SDOD_REQUIRE(x && y && n > 0 && c > 0 && hw > 0, "bad argument");
     LAUNCH(nchw_to_nhwc_kernel, (size_t)n * c * hw, stream, x, (f16*)y, n, c, hw, scale);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_latent_prep_f16(const float* x, const float* w, const float* b, void* y, int n, int c, int hw, float scale,
+                                    void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(x && y && n > 0 && c > 0 && c <= 16 && hw > 0, "bad argument");
+    LAUNCH(latent_prep_kernel, (size_t)n * c * hw, stream, x, w, b, (f16*)y, n, c, hw, scale);
     return 0;
     SDOD_CATCH
 }

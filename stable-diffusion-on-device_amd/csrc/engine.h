@@ -1,0 +1,159 @@
+// engine.h -- the graph engine behind include/sdod_engine.h: weight arena, activation arena, launch list.
+// It replaces, for MI355X, what QnnBackend/QnnGraph/QnnTensor do for the Hexagon HTP in the reference
+// (csrc/libsdod/src/qnn_context.{h,cpp}): "load a graph, own its I/O tensors, execute it".
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "host_util.h"
+#include "sdod_engine.h"
+#include "sdod_hip.h"
+
+namespace sdod {
+
+typedef _Float16 f16;
+
+enum ParamKind {
+    PK_CONV3,       // [Cout][Cin][3][3] -> fp16 [Cout][(r*3+s)*Cin + c]
+    PK_CONV3_SMALL, // Cin < 64: same order, K zero-padded to 64
+    PK_CONV1,       // [Cout][Cin][1][1] -> fp16 [Cout][Cin]
+    PK_LINEAR,      // [out][in] -> fp16
+    PK_EMBED,       // [rows][dim] -> fp16
+    PK_VEC,         // [n] -> fp32
+    PK_MAT_F32,     // small matrix kept in fp32 (post_quant_conv 4x4)
+};
+
+struct Param {
+    std::string name;
+    std::vector<int64_t> shape; // canonical (PyTorch) shape
+    ParamKind kind;
+    int group = -1;
+    size_t dev_bytes = 0;
+    char* dev = nullptr;
+    bool set = false;
+};
+
+// activation tensor: NHWC fp16 (sequences: h = 1, w = tokens)
+struct Act {
+    f16* p = nullptr;
+    int n = 0, h = 0, w = 0, c = 0;
+    int rows() const { return n * h * w; }
+    size_t numel() const { return (size_t)rows() * c; }
+};
+
+struct IoSlot {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+class Graph {
+public:
+    Graph(int kind, const sdod_model_config& cfg, int batch);
+    ~Graph();
+    Graph(const Graph&) = delete;
+
+    int num_params() const { return (int)params_.size(); }
+    const Param& param(int i) const { return params_.at(i); }
+    void set_param(const std::string& name, const void* data, int dtype, const int64_t* shape, int ndim);
+    void load_file(const std::string& path, const std::string& prefix);
+    void finalize();
+    void execute(hipStream_t st, bool use_hip_graph);
+    IoSlot io(bool output, int index) const;
+    void stats(size_t* wbytes, size_t* abytes, int* launches, double* flops) const;
+
+private:
+    enum Mode { DECLARE, DRY, REAL };
+    int kind_;
+    sdod_model_config cfg_;
+    int batch_;
+    Mode mode_ = DECLARE;
+    bool finalized_ = false;
+
+    // ---- parameters
+    std::vector<Param> params_;
+    std::unordered_map<std::string, int> pindex_;
+    std::vector<std::vector<int>> groups_;
+    std::unordered_map<std::string, int> gindex_;
+    char* weight_base_ = nullptr;
+    size_t weight_bytes_ = 0;
+    int P(const std::string& name, std::vector<int64_t> shape, ParamKind kind, const std::string& group = "");
+    template <typename T>
+    const T* W(int idx) const { return reinterpret_cast<const T*>(params_[idx].dev); }
+    void allocate_weights();
+
+    // ---- activation arena (first-fit free list; DRY mode only measures the high-water mark)
+    char* arena_base_ = nullptr;
+    size_t arena_cap_ = 0, arena_high_ = 0;
+    std::map<size_t, size_t> free_;   // offset -> size
+    std::map<size_t, size_t> used_;   // offset -> size
+    void arena_reset();
+    f16* alloc(size_t halves);
+    void release(const void* p);
+    Act act(int n, int h, int w, int c);
+    void release(const Act& a) { release(a.p); }
+
+    // ---- scratch
+    char* ws_ = nullptr;      // split-K slabs
+    size_t ws_bytes_ = 0, ws_need_ = 0;
+    char* gn_ws_ = nullptr;   // GroupNorm partials
+    size_t gn_ws_bytes_ = 0, gn_ws_need_ = 0;
+
+    // ---- io
+    std::vector<IoSlot> inputs_, outputs_;
+    void* io_alloc(std::vector<IoSlot>& v, size_t bytes);
+
+    // ---- launch list
+    std::vector<std::function<void(hipStream_t)>> ops_;
+    double flops_ = 0;
+    hipGraphExec_t graph_exec_ = nullptr;
+    hipGraph_t hip_graph_ = nullptr;
+    hipStream_t capture_stream_ = nullptr;
+    int eager_runs_ = 0;
+
+    void build();       // dispatches on kind_
+    void build_unet();
+    void build_vae();
+    void build_clip();
+    void build_temb();
+
+    // ---- op emitters (record in REAL mode, account in DRY mode, nothing in DECLARE mode)
+    struct GemmOpt {
+        int bias = -1;             // param index (PK_VEC) or -1
+        const float* bias_raw = nullptr; // raw fp32 bias pointer (fused parameter groups)
+        f16* out = nullptr;        // conv(): write here instead of allocating from the arena
+        const f16* row_bias = nullptr;
+        int ld_row_bias = 0, rows_per_img = 0;
+        const f16* residual = nullptr;
+        int act = 0;
+        float alpha = 1.0f;
+        bool bias_on_m = false;
+        int lda = 0, ldo = 0;      // 0 = dense
+    };
+    void emit_gemm(sdod_gemm_desc d);
+    // out[rows][N] = x[rows][K] . W^T ; W is params_[w] (or a raw fp16 [N][K] pointer through *_raw)
+    void linear(const f16* x, int rows, int K, int w, int N, f16* out, const GemmOpt& o);
+    void linear_raw(const f16* x, int rows, int K, const f16* w, int ldw, int N, f16* out, const GemmOpt& o);
+    // NHWC conv through the gather GEMM (ksize 1 or 3); x2 = optional concat source
+    Act conv(const Act& x, const Act* x2, int w, int cout, int ksize, int stride, bool upsample, const GemmOpt& o);
+    Act group_norm(const Act& x, const Act* x2, int gw, int gb, float eps, bool silu);
+    Act layer_norm(const Act& x, int lw, int lb, float eps);
+    void attention(const f16* q, const f16* k, const f16* v, f16* out, int B, int heads, int lq, int lk, int d, int ldq,
+                   int ldk, int ldv, int ldo, bool causal);
+
+    // ---- model blocks
+    Act res_block(const std::string& pfx, const Act& x, const Act* x2, int cout, const f16* emb_all, int emb_ld, int& emb_off);
+    Act spatial_transformer(const std::string& pfx, const Act& x, const Act& ctx);
+    Act vae_res_block(const std::string& pfx, const Act& x, int cout);
+    Act vae_attn_block(const std::string& pfx, const Act& x);
+    int emb_total_ = 0; // sum of ResBlock output channels (set by the DECLARE pass)
+    const char* group_base(const std::string& group) const;
+    void emit(std::function<void(hipStream_t)> fn) { if (mode_ == REAL) ops_.push_back(std::move(fn)); }
+};
+
+} // namespace sdod

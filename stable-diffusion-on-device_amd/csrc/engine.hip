@@ -1,0 +1,594 @@
+// engine.hip -- core of the graph engine: parameters, arenas, op emitters, execution (see engine.h).
+#include "engine.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstring>
+#include <thread>
+
+namespace sdod {
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void check_rc(int rc) {
+    if (rc != 0) throw Error(rc, get_last_error());
+}
+
+template <typename F>
+static void parallel_for(int64_t n, F&& fn) {
+    int nt = (int)std::min<int64_t>(n, std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+    if (nt <= 1) {
+        fn(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int64_t per = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        const int64_t b = t * per, e = std::min(n, b + per);
+        if (b < e) th.emplace_back([=, &fn]() { fn(b, e); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// ------------------------------------------------------------------------------------------ lifecycle
+Graph::Graph(int kind, const sdod_model_config& cfg, int batch) : kind_(kind), cfg_(cfg), batch_(batch) {
+    SDOD_REQUIRE(kind >= SDOD_GRAPH_UNET && kind <= SDOD_GRAPH_TEMB, "unknown graph kind");
+    SDOD_REQUIRE(batch > 0 && batch <= 64, "batch must be in [1, 64]");
+    SDOD_REQUIRE(cfg.model_channels > 0 && cfg.model_channels % 64 == 0, "model_channels must be a multiple of 64");
+    SDOD_REQUIRE(cfg.context_dim % 64 == 0, "context_dim must be a multiple of 64");
+    mode_ = DECLARE;
+    arena_reset();
+    build();
+    allocate_weights();
+}
+
+Graph::~Graph() {
+    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    if (capture_stream_) (void)hipStreamDestroy(capture_stream_);
+    if (hip_graph_) (void)hipGraphDestroy(hip_graph_);
+    for (auto& s : inputs_) (void)hipFree(s.ptr);
+    for (auto& s : outputs_) (void)hipFree(s.ptr);
+    (void)hipFree(weight_base_);
+    (void)hipFree(arena_base_);
+    (void)hipFree(ws_);
+    (void)hipFree(gn_ws_);
+}
+
+// ------------------------------------------------------------------------------------------ parameters
+static size_t param_dev_bytes(const Param& p) {
+    const auto& s = p.shape;
+    switch (p.kind) {
+    case PK_CONV3: return (size_t)s[0] * s[1] * 9 * sizeof(f16);
+    case PK_CONV3_SMALL: return (size_t)s[0] * 64 * sizeof(f16);
+    case PK_CONV1:
+    case PK_LINEAR:
+    case PK_EMBED: return (size_t)s[0] * s[1] * sizeof(f16);
+    case PK_VEC: return (size_t)s[0] * sizeof(float);
+    case PK_MAT_F32: {
+        size_t n = 1;
+        for (auto d : s) n *= (size_t)d;
+        return n * sizeof(float);
+    }
+    }
+    return 0;
+}
+
+int Graph::P(const std::string& name, std::vector<int64_t> shape, ParamKind kind, const std::string& group) {
+    if (mode_ != DECLARE) {
+        auto it = pindex_.find(name);
+        if (it == pindex_.end()) throw Error(INTERNAL_ERROR, "parameter not declared: " + name);
+        return it->second;
+    }
+    if (pindex_.count(name)) throw Error(INTERNAL_ERROR, "duplicate parameter: " + name);
+    Param p;
+    p.name = name;
+    p.shape = std::move(shape);
+    p.kind = kind;
+    p.dev_bytes = param_dev_bytes(p);
+    if (!group.empty()) {
+        auto it = gindex_.find(group);
+        if (it == gindex_.end()) {
+            gindex_[group] = (int)groups_.size();
+            groups_.emplace_back();
+            it = gindex_.find(group);
+        }
+        p.group = it->second;
+        groups_[p.group].push_back((int)params_.size());
+    }
+    pindex_[name] = (int)params_.size();
+    params_.push_back(std::move(p));
+    return (int)params_.size() - 1;
+}
+
+void Graph::allocate_weights() {
+    // groups first (members contiguous, declaration order), then everything else; 256-byte alignment per block
+    size_t off = 0;
+    std::vector<size_t> offs(params_.size(), 0);
+    for (auto& g : groups_) {
+        off = align_up(off, 256);
+        for (int idx : g) {
+            if (params_[idx].dev_bytes % 16) throw Error(INTERNAL_ERROR, "grouped parameter size must be a multiple of 16: " + params_[idx].name);
+            offs[idx] = off;
+            off += params_[idx].dev_bytes;
+        }
+    }
+    for (size_t i = 0; i < params_.size(); ++i) {
+        if (params_[i].group >= 0) continue;
+        off = align_up(off, 256);
+        offs[i] = off;
+        off += params_[i].dev_bytes;
+    }
+    weight_bytes_ = align_up(off, 256);
+    SDOD_HIP_CHECK(hipMalloc((void**)&weight_base_, weight_bytes_));
+    SDOD_HIP_CHECK(hipMemset(weight_base_, 0, weight_bytes_));
+    for (size_t i = 0; i < params_.size(); ++i) params_[i].dev = weight_base_ + offs[i];
+}
+
+template <typename S>
+static void pack_param_host(const Param& p, const S* src, char* dst_raw) {
+    const auto& s = p.shape;
+    switch (p.kind) {
+    case PK_CONV3:
+    case PK_CONV3_SMALL: {
+        const int64_t co = s[0], ci = s[1];
+        const int64_t kd = p.kind == PK_CONV3 ? 9 * ci : 64;
+        f16* dst = reinterpret_cast<f16*>(dst_raw);
+        parallel_for(co, [&](int64_t b, int64_t e) {
+            for (int64_t o = b; o < e; ++o) {
+                f16* drow = dst + o * kd;
+                if (p.kind == PK_CONV3_SMALL) std::memset(drow, 0, kd * sizeof(f16));
+                const S* srow = src + o * ci * 9;
+                for (int64_t c = 0; c < ci; ++c)
+                    for (int t = 0; t < 9; ++t) drow[t * ci + c] = (f16)(float)srow[c * 9 + t];
+            }
+        });
+        break;
+    }
+    case PK_CONV1:
+    case PK_LINEAR:
+    case PK_EMBED: {
+        const int64_t n = s[0] * s[1];
+        f16* dst = reinterpret_cast<f16*>(dst_raw);
+        parallel_for(n, [&](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i) dst[i] = (f16)(float)src[i];
+        });
+        break;
+    }
+    case PK_VEC:
+    case PK_MAT_F32: {
+        int64_t n = 1;
+        for (auto d : s) n *= d;
+        float* dst = reinterpret_cast<float*>(dst_raw);
+        for (int64_t i = 0; i < n; ++i) dst[i] = (float)src[i];
+        break;
+    }
+    }
+}
+
+void Graph::set_param(const std::string& name, const void* data, int dtype, const int64_t* shape, int ndim) {
+    auto it = pindex_.find(name);
+    SDOD_REQUIRE(it != pindex_.end(), "unknown parameter '" + name + "'");
+    SDOD_REQUIRE(data != nullptr, "null data for '" + name + "'");
+    SDOD_REQUIRE(dtype == SDOD_F32 || dtype == SDOD_F16, "dtype must be SDOD_F32 or SDOD_F16");
+    Param& p = params_[it->second];
+    int64_t want = 1, got = 1;
+    for (auto d : p.shape) want *= d;
+    for (int i = 0; i < ndim; ++i) got *= shape[i];
+    bool same = (int)p.shape.size() == ndim;
+    for (int i = 0; same && i < ndim; ++i) same = p.shape[i] == shape[i];
+    // a [Cout][Cin] matrix is accepted for a 1x1 conv and vice versa (SD2.x stores proj_in/out as Linear)
+    if (!same && want == got && (p.kind == PK_CONV1 || p.kind == PK_LINEAR) && ndim >= 2 && shape[0] == p.shape[0]) same = true;
+    if (!same) {
+        std::string m = "shape mismatch for '" + name + "': expected [";
+        for (auto d : p.shape) m += std::to_string(d) + ",";
+        m += "] got [";
+        for (int i = 0; i < ndim; ++i) m += std::to_string(shape[i]) + ",";
+        throw Error(INVALID_ARGUMENT, m + "]");
+    }
+    std::vector<char> staging(p.dev_bytes);
+    if (dtype == SDOD_F32) pack_param_host(p, reinterpret_cast<const float*>(data), staging.data());
+    else pack_param_host(p, reinterpret_cast<const f16*>(data), staging.data());
+    SDOD_HIP_CHECK(hipMemcpy(p.dev, staging.data(), p.dev_bytes, hipMemcpyHostToDevice));
+    p.set = true;
+}
+
+// .sdodw container: "SDODW001", u64 count, then per tensor {u32 name_len, name, u32 dtype, u32 ndim, u64 dims[ndim],
+// u64 offset, u64 nbytes}; payloads at absolute file offsets.  Written by sdod.amd.weights.save().
+void Graph::load_file(const std::string& path, const std::string& prefix) {
+    int fd = ::open(path.c_str(), O_RDONLY);
+    SDOD_REQUIRE(fd >= 0, "cannot open weight file " + path);
+    struct stat stt;
+    if (fstat(fd, &stt) != 0) {
+        ::close(fd);
+        throw Error(INVALID_ARGUMENT, "cannot stat " + path);
+    }
+    const size_t fsize = (size_t)stt.st_size;
+    void* map = mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    SDOD_REQUIRE(map != MAP_FAILED, "mmap failed for " + path);
+    struct Unmap {
+        void* p;
+        size_t n;
+        ~Unmap() { munmap(p, n); }
+    } guard{map, fsize};
+    const char* base = static_cast<const char*>(map);
+    size_t pos = 0;
+    auto need = [&](size_t n) { SDOD_REQUIRE(pos + n <= fsize, "truncated weight file " + path); };
+    need(16);
+    SDOD_REQUIRE(std::memcmp(base, "SDODW001", 8) == 0, "bad magic in " + path);
+    uint64_t count;
+    std::memcpy(&count, base + 8, 8);
+    pos = 16;
+    for (uint64_t t = 0; t < count; ++t) {
+        uint32_t nl, dt, nd;
+        need(4); std::memcpy(&nl, base + pos, 4); pos += 4;
+        need(nl); std::string name(base + pos, nl); pos += nl;
+        need(8); std::memcpy(&dt, base + pos, 4); std::memcpy(&nd, base + pos + 4, 4); pos += 8;
+        SDOD_REQUIRE(nd <= 8, "bad ndim in " + path);
+        int64_t dims[8];
+        need(8 * nd + 16);
+        for (uint32_t i = 0; i < nd; ++i) { uint64_t d; std::memcpy(&d, base + pos, 8); pos += 8; dims[i] = (int64_t)d; }
+        uint64_t off, nb;
+        std::memcpy(&off, base + pos, 8); std::memcpy(&nb, base + pos + 8, 8); pos += 16;
+        SDOD_REQUIRE(off + nb <= fsize, "tensor payload out of range in " + path);
+        if (name.compare(0, prefix.size(), prefix) != 0) continue;
+        const std::string local = name.substr(prefix.size());
+        if (!pindex_.count(local)) continue;
+        set_param(local, base + off, (int)dt, dims, (int)nd);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ arenas
+static char* const kFakeBase = reinterpret_cast<char*>(uintptr_t(1) << 40);
+
+void Graph::arena_reset() {
+    free_.clear();
+    used_.clear();
+    if (mode_ == REAL) {
+        free_[0] = arena_cap_;
+    } else {
+        free_[0] = size_t(1) << 39;
+        arena_high_ = 0;
+    }
+}
+
+f16* Graph::alloc(size_t halves) {
+    const size_t bytes = align_up(std::max<size_t>(halves * sizeof(f16), 256), 256);
+    for (auto it = free_.begin(); it != free_.end(); ++it) {
+        if (it->second >= bytes) {
+            const size_t off = it->first, sz = it->second;
+            free_.erase(it);
+            if (sz > bytes) free_[off + bytes] = sz - bytes;
+            used_[off] = bytes;
+            arena_high_ = std::max(arena_high_, off + bytes);
+            char* base = mode_ == REAL ? arena_base_ : kFakeBase;
+            return reinterpret_cast<f16*>(base + off);
+        }
+    }
+    throw Error(INTERNAL_ERROR, "activation arena exhausted");
+}
+
+void Graph::release(const void* p) {
+    if (!p) return;
+    char* base = mode_ == REAL ? arena_base_ : kFakeBase;
+    const size_t off = (size_t)(reinterpret_cast<const char*>(p) - base);
+    auto it = used_.find(off);
+    if (it == used_.end()) throw Error(INTERNAL_ERROR, "arena release of unknown block");
+    size_t sz = it->second;
+    used_.erase(it);
+    size_t start = off;
+    auto nxt = free_.lower_bound(off);
+    if (nxt != free_.end() && nxt->first == off + sz) {
+        sz += nxt->second;
+        nxt = free_.erase(nxt);
+    }
+    if (nxt != free_.begin()) {
+        auto prv = std::prev(nxt);
+        if (prv->first + prv->second == off) {
+            start = prv->first;
+            sz += prv->second;
+            free_.erase(prv);
+        }
+    }
+    free_[start] = sz;
+}
+
+Act Graph::act(int n, int h, int w, int c) {
+    Act a;
+    a.n = n; a.h = h; a.w = w; a.c = c;
+    a.p = alloc(a.numel());
+    return a;
+}
+
+void* Graph::io_alloc(std::vector<IoSlot>& v, size_t bytes) {
+    IoSlot s;
+    s.bytes = bytes;
+    if (mode_ == REAL) {
+        SDOD_HIP_CHECK(hipMalloc(&s.ptr, align_up(bytes, 256)));
+        SDOD_HIP_CHECK(hipMemset(s.ptr, 0, align_up(bytes, 256)));
+        v.push_back(s);
+        return s.ptr;
+    }
+    return kFakeBase + (size_t(1) << 39) + v.size() * 4096; // never dereferenced
+}
+
+IoSlot Graph::io(bool output, int index) const {
+    const auto& v = output ? outputs_ : inputs_;
+    SDOD_REQUIRE(finalized_, "graph not finalized");
+    SDOD_REQUIRE(index >= 0 && index < (int)v.size(), "io index out of range");
+    return v[index];
+}
+
+// ------------------------------------------------------------------------------------------ emitters
+void Graph::emit_gemm(sdod_gemm_desc d) {
+    if (mode_ == DECLARE) return;
+    ws_need_ = std::max(ws_need_, sdod_gemm_workspace_bytes(&d));
+    if (mode_ != REAL) return;
+    flops_ += 2.0 * d.M * d.N * d.K;
+    d.workspace = ws_;
+    d.workspace_bytes = ws_bytes_;
+    ops_.push_back([d](hipStream_t st) { check_rc(sdod_gemm_f16(&d, st)); });
+}
+
+void Graph::linear_raw(const f16* x, int rows, int K, const f16* w, int ldw, int N, f16* out, const GemmOpt& o) {
+    sdod_gemm_desc d{};
+    d.a = x; d.w = w; d.out = out;
+    d.M = rows; d.N = N; d.K = K;
+    d.lda = o.lda ? o.lda : K;
+    d.ldw = ldw;
+    d.ldo = o.ldo ? o.ldo : N;
+    d.a_mode = SDOD_A_ROWS;
+    if (o.bias >= 0) d.bias = params_[o.bias].dev;
+    if (o.bias_raw) d.bias = o.bias_raw;
+    d.bias_on_m = o.bias_on_m ? 1 : 0;
+    d.row_bias = o.row_bias; d.ld_row_bias = o.ld_row_bias; d.rows_per_img = o.rows_per_img;
+    d.residual = o.residual; d.ldr = d.ldo;
+    d.act = o.act; d.alpha = o.alpha;
+    emit_gemm(d);
+}
+
+void Graph::linear(const f16* x, int rows, int K, int w, int N, f16* out, const GemmOpt& o) {
+    const Param& p = params_[w];
+    const int ldw = p.kind == PK_CONV3_SMALL ? 64 : (int)(p.kind == PK_CONV3 ? p.shape[1] * 9 : p.shape[1]);
+    linear_raw(x, rows, K, reinterpret_cast<const f16*>(p.dev), ldw, N, out, o);
+}
+
+Act Graph::conv(const Act& x, const Act* x2, int w, int cout, int ksize, int stride, bool upsample, const GemmOpt& o) {
+    const int ups = upsample ? 1 : 0;
+    const int hup = x.h << ups, wup = x.w << ups;
+    const int ho = (hup + 2 * (ksize / 2) - ksize) / stride + 1, wo = (wup + 2 * (ksize / 2) - ksize) / stride + 1;
+    Act y;
+    y.n = x.n; y.h = ho; y.w = wo; y.c = cout;
+    y.p = o.out ? o.out : alloc(y.numel());
+    sdod_gemm_desc d{};
+    d.a = x.p; d.a2 = x2 ? x2->p : nullptr;
+    d.w = params_[w].dev; d.out = y.p;
+    const int cin = x.c + (x2 ? x2->c : 0);
+    d.M = y.rows(); d.N = cout; d.K = ksize * ksize * cin;
+    d.ldw = d.K; d.ldo = cout;
+    d.a_mode = SDOD_A_CONV3X3;
+    d.n_img = x.n; d.h_in = x.h; d.w_in = x.w; d.c0 = x.c; d.c1 = x2 ? x2->c : 0;
+    d.stride = stride; d.upsample = ups; d.ksize = ksize;
+    if (o.bias >= 0) d.bias = params_[o.bias].dev;
+    d.row_bias = o.row_bias; d.ld_row_bias = o.ld_row_bias; d.rows_per_img = o.rows_per_img;
+    d.residual = o.residual; d.ldr = cout;
+    d.act = o.act; d.alpha = o.alpha;
+    emit_gemm(d);
+    return y;
+}
+
+Act Graph::group_norm(const Act& x, const Act* x2, int gw, int gb, float eps, bool silu) {
+    Act y = act(x.n, x.h, x.w, x.c + (x2 ? x2->c : 0));
+    if (mode_ == DECLARE) return y;
+    gn_ws_need_ = std::max(gn_ws_need_, sdod_group_norm_workspace_bytes(x.n, 32));
+    if (mode_ != REAL) return y;
+    const void* xp = x.p; const void* x2p = x2 ? x2->p : nullptr; void* yp = y.p;
+    const float* wp = W<float>(gw); const float* bp = W<float>(gb);
+    const int n = x.n, hw = x.h * x.w, c0 = x.c, c1 = x2 ? x2->c : 0, si = silu ? 1 : 0;
+    void* ws = gn_ws_;
+    ops_.push_back([=](hipStream_t st) {
+        check_rc(sdod_group_norm_nhwc(xp, x2p, yp, wp, bp, n, hw, c0, c1, 32, eps, si, SDOD_F16, ws, st));
+    });
+    return y;
+}
+
+Act Graph::layer_norm(const Act& x, int lw, int lb, float eps) {
+    Act y = act(x.n, x.h, x.w, x.c);
+    if (mode_ != REAL) return y;
+    const void* xp = x.p; void* yp = y.p;
+    const float* wp = W<float>(lw); const float* bp = W<float>(lb);
+    const int m = x.rows(), c = x.c;
+    ops_.push_back([=](hipStream_t st) { check_rc(sdod_layer_norm_f16(xp, yp, wp, bp, m, c, eps, st)); });
+    return y;
+}
+
+void Graph::attention(const f16* q, const f16* k, const f16* v, f16* out, int B, int heads, int lq, int lk, int d, int ldq,
+                      int ldk, int ldv, int ldo, bool causal) {
+    if (mode_ != REAL) return;
+    flops_ += 4.0 * B * heads * (double)lq * lk * d;
+    const float scale = 1.0f / sqrtf((float)d);
+    const int ca = causal ? 1 : 0;
+    ops_.push_back([=](hipStream_t st) {
+        check_rc(sdod_attention_f16(q, k, v, out, B, heads, lq, lk, d, ldq, ldk, ldv, ldo, scale, ca, st));
+    });
+}
+
+// ------------------------------------------------------------------------------------------ finalize / run
+void Graph::build() {
+    switch (kind_) {
+    case SDOD_GRAPH_UNET: build_unet(); break;
+    case SDOD_GRAPH_VAE_DECODER: build_vae(); break;
+    case SDOD_GRAPH_TEXT_ENCODER: build_clip(); break;
+    default: build_temb(); break;
+    }
+}
+
+void Graph::finalize() {
+    SDOD_REQUIRE(!finalized_, "graph already finalized");
+    std::string missing;
+    int nmiss = 0;
+    for (auto& p : params_)
+        if (!p.set) {
+            if (nmiss < 5) missing += (nmiss ? ", " : "") + p.name;
+            ++nmiss;
+        }
+    SDOD_REQUIRE(nmiss == 0, std::to_string(nmiss) + " parameter(s) not set: " + missing + (nmiss > 5 ? ", ..." : ""));
+    mode_ = DRY;
+    arena_reset();
+    ws_need_ = gn_ws_need_ = 0;
+    build();
+    arena_cap_ = align_up(arena_high_, 256) + 256;
+    ws_bytes_ = align_up(ws_need_, 256) + 256;
+    gn_ws_bytes_ = align_up(gn_ws_need_, 256) + 256;
+    SDOD_HIP_CHECK(hipMalloc((void**)&arena_base_, arena_cap_));
+    SDOD_HIP_CHECK(hipMalloc((void**)&ws_, ws_bytes_));
+    SDOD_HIP_CHECK(hipMalloc((void**)&gn_ws_, gn_ws_bytes_));
+    mode_ = REAL;
+    arena_reset();
+    ops_.clear();
+    flops_ = 0;
+    build();
+    finalized_ = true;
+}
+
+void Graph::execute(hipStream_t st, bool use_hip_graph) {
+    SDOD_REQUIRE(finalized_, "graph not finalized");
+    if (!use_hip_graph || eager_runs_ == 0) {
+        // the first run is always eager: it sets kernel attributes (dynamic LDS sizes), which must not happen in capture
+        for (auto& op : ops_) op(st);
+        ++eager_runs_;
+        return;
+    }
+    if (!graph_exec_) {
+        // capture on a private stream (the caller's may be the legacy default stream, which cannot capture);
+        // kernel nodes carry no stream identity, so the instantiated graph replays on any stream
+        if (!capture_stream_) SDOD_HIP_CHECK(hipStreamCreateWithFlags(&capture_stream_, hipStreamNonBlocking));
+        SDOD_HIP_CHECK(hipStreamSynchronize(st));
+        SDOD_HIP_CHECK(hipStreamBeginCapture(capture_stream_, hipStreamCaptureModeThreadLocal));
+        try {
+            for (auto& op : ops_) op(capture_stream_);
+        } catch (...) {
+            hipGraph_t g = nullptr;
+            (void)hipStreamEndCapture(capture_stream_, &g);
+            if (g) (void)hipGraphDestroy(g);
+            throw;
+        }
+        SDOD_HIP_CHECK(hipStreamEndCapture(capture_stream_, &hip_graph_));
+        SDOD_HIP_CHECK(hipGraphInstantiate(&graph_exec_, hip_graph_, nullptr, nullptr, 0));
+    }
+    SDOD_HIP_CHECK(hipGraphLaunch(graph_exec_, st));
+}
+
+void Graph::stats(size_t* wbytes, size_t* abytes, int* launches, double* flops) const {
+    if (wbytes) *wbytes = weight_bytes_;
+    if (abytes) *abytes = arena_cap_;
+    if (launches) *launches = (int)ops_.size();
+    if (flops) *flops = flops_;
+}
+
+} // namespace sdod
+
+// ================================================================================================ C ABI
+using sdod::Graph;
+
+extern "C" void sdod_model_config_sd14(sdod_model_config* cfg) {
+    if (!cfg) return;
+    cfg->latent_channels = 4;
+    cfg->latent_h = 64;
+    cfg->latent_w = 64;
+    cfg->model_channels = 320;
+    cfg->context_dim = 768;
+    cfg->context_len = 77;
+    cfg->num_heads = 8;
+    cfg->head_dim = 0;
+    cfg->vocab_size = 49408;
+    cfg->text_layers = 12;
+    cfg->text_heads = 12;
+    cfg->vae_channels = 128;
+}
+
+extern "C" int sdod_graph_create(void** graph, int kind, const sdod_model_config* cfg, int batch) {
+    SDOD_TRY
+    SDOD_REQUIRE(graph != nullptr && cfg != nullptr, "null argument");
+    *graph = nullptr;
+    *graph = new Graph(kind, *cfg, batch);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_graph_destroy(void* graph) {
+    SDOD_TRY
+    delete static_cast<Graph*>(graph);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_graph_num_params(void* graph) { return graph ? static_cast<Graph*>(graph)->num_params() : 0; }
+
+extern "C" int sdod_graph_param_info(void* graph, int index, const char** name, int* ndim, int64_t shape[4]) {
+    SDOD_TRY
+    SDOD_REQUIRE(graph != nullptr, "null graph");
+    auto* g = static_cast<Graph*>(graph);
+    SDOD_REQUIRE(index >= 0 && index < g->num_params(), "parameter index out of range");
+    const sdod::Param& p = g->param(index);
+    if (name) *name = p.name.c_str();
+    if (ndim) *ndim = (int)p.shape.size();
+    if (shape)
+        for (size_t i = 0; i < 4; ++i) shape[i] = i < p.shape.size() ? p.shape[i] : 1;
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_graph_set_param(void* graph, const char* name, const void* data, int dtype, const int64_t* shape, int ndim) {
+    SDOD_TRY
+    SDOD_REQUIRE(graph && name && shape, "null argument");
+    static_cast<Graph*>(graph)->set_param(name, data, dtype, shape, ndim);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_graph_load_file(void* graph, const char* path, const char* prefix) {
+    SDOD_TRY
+    SDOD_REQUIRE(graph && path, "null argument");
+    static_cast<Graph*>(graph)->load_file(path, prefix ? prefix : "");
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_graph_finalize(void* graph) {
+    SDOD_TRY
+    SDOD_REQUIRE(graph != nullptr, "null graph");
+    static_cast<Graph*>(graph)->finalize();
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_graph_io(void* graph, int is_output, int index, void** device_ptr, size_t* bytes) {
+    SDOD_TRY
+    SDOD_REQUIRE(graph != nullptr, "null graph");
+    const sdod::IoSlot s = static_cast<Graph*>(graph)->io(is_output != 0, index);
+    if (device_ptr) *device_ptr = s.ptr;
+    if (bytes) *bytes = s.bytes;
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_graph_execute(void* graph, void* stream, int use_hip_graph) {
+    SDOD_TRY
+    SDOD_REQUIRE(graph != nullptr, "null graph");
+    static_cast<Graph*>(graph)->execute((hipStream_t)stream, use_hip_graph != 0);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_graph_stats(void* graph, size_t* weight_bytes, size_t* arena_bytes, int* num_launches, double* flops) {
+    SDOD_TRY
+    SDOD_REQUIRE(graph != nullptr, "null graph");
+    static_cast<Graph*>(graph)->stats(weight_bytes, arena_bytes, num_launches, flops);
+    return 0;
+    SDOD_CATCH
+}

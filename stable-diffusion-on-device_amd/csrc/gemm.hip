@@ -9,8 +9,8 @@
 //     v_mfma_f32_16x16x32_f16 (fp32 accumulate in the unified VGPR/AGPR file);
 //   * K is walked in BK=64 slabs; both operands are K-contiguous, so a slab row is one 128-byte line.
 //     For the 3x3 conv the slab of row m=(img,oy,ox) is the 128-byte channel run of ONE input pixel
-//     (tap (r,s), channels c..c+63) -- im2col never exists in HBM; nearest-2x upsampling, stride 2 and a
-//     two-tensor channel concat are folded into the same address computation;
+//     (tap (r,s), channels c..c+63) -- im2col never exists in HBM; nearest-2x upsampling, stride 2, a
+//     two-tensor channel concat and the 1x1 case (ksize 1) are folded into the same address computation;
 //   * slabs are staged global -> registers -> LDS (double-buffered, one barrier per slab; the loads for
 //     slab t+1 are issued before the MFMAs of slab t), LDS rows are XOR-swizzled in 16-byte chunks so
 //     the ds_read_b128 fragment reads are bank-conflict free;
@@ -32,15 +32,15 @@ struct GemmP {
     const f16* a1;
     const f16* w;
     const float* bias;
-    const float* row_bias;
+    const f16* row_bias;
     const f16* residual;
     f16* out;
     float* partial;
     int M, N, K;
     int lda, ldw, ldo, ldr;
     int mode;
-    int h_in, w_in, h_out, w_out, c0, c1, stride, ups;
-    int rows_per_img;
+    int h_in, w_in, h_out, w_out, c0, c1, stride, ups, ksize;
+    int rows_per_img, ldrb;
     int act;
     float alpha;
     int bias_on_m;
@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         if (p.mode == SDOD_A_CONV3X3) {
             const int tap = k0 / cin;
             const int cc = k0 - tap * cin;
-            const int r = tap / 3, s = tap - r * 3;
+            const int r = tap / p.ksize, s = tap - r * p.ksize;
+            const int pad = p.ksize >> 1;
             const f16* src = p.a0;
             int csrc = p.c0, ccs = cc;
             if (cc >= p.c0) {
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
             }
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
-                int yy = a_oy[i] + r - 1, xx = a_ox[i] + s - 1;
+                int yy = a_oy[i] + r - pad, xx = a_ox[i] + s - pad;
                 const bool ok = a_ok[i] && yy >= 0 && yy < hup && xx >= 0 && xx < wup;
                 yy >>= p.ups;
                 xx >>= p.ups;
@@ -239,8 +240,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     for (int i = 0; i < TM; ++i) {
         const int ml = wm * WTM + i * 16 + e_m;
         const int m = m0 + ml;
-        const float* rbias = nullptr;
-        if (p.row_bias != nullptr && m < p.M) rbias = p.row_bias + (size_t)(m / p.rows_per_img) * p.N;
+        const f16* rbias = nullptr;
+        if (p.row_bias != nullptr && m < p.M) rbias = p.row_bias + (size_t)(m / p.rows_per_img) * p.ldrb;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nl = wn * WTN + j * 16 + e_n;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
                         v += p.bias[n + r];
                     }
                 }
-                if (rbias != nullptr && n + r < p.N) v += rbias[n + r];
+                if (rbias != nullptr && n + r < p.N) v += (float)rbias[n + r];
                 v = apply_act(v, p.act);
                 h[r] = (f16)v;
             }
@@ -311,12 +312,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
                     if (n + r < p.N) v[r] += src[r];
             }
         }
-        const float* rbias = p.row_bias ? p.row_bias + (size_t)(m / p.rows_per_img) * p.N : nullptr;
+        const f16* rbias = p.row_bias ? p.row_bias + (size_t)(m / p.rows_per_img) * p.ldrb : nullptr;
         for (int r = 0; r < 4; ++r) {
             if (n + r >= p.N) break;
             float f = v[r] * p.alpha;
             if (p.bias) f += p.bias_on_m ? p.bias[m] : p.bias[n + r];
-            if (rbias) f += rbias[n + r];
+            if (rbias) f += (float)rbias[n + r];
             f = apply_act(f, p.act);
             f = (float)(f16)f; // same rounding point as the un-split path
             if (p.residual) f += (float)p.residual[(size_t)m * p.ldr + n + r];
@@ -409,7 +410,8 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     p.a1 = (const f16*)d->a2;
     p.w = (const f16*)d->w;
     p.bias = (const float*)d->bias;
-    p.row_bias = (const float*)d->row_bias;
+    p.row_bias = (const f16*)d->row_bias;
+    p.ldrb = d->ld_row_bias > 0 ? d->ld_row_bias : d->N;
     p.residual = (const f16*)d->residual;
     p.out = (f16*)d->out;
     p.M = d->M; p.N = d->N; p.K = d->K;
@@ -425,18 +427,21 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         SDOD_REQUIRE(d->stride == 1 || d->stride == 2, "conv stride must be 1 or 2");
         SDOD_REQUIRE(d->c0 > 0 && d->c0 % 64 == 0 && d->c1 % 64 == 0, "conv channels must be multiples of 64");
         SDOD_REQUIRE(d->a2 != nullptr || d->c1 == 0, "c1 > 0 needs a2");
-        SDOD_REQUIRE(d->K == 9 * (d->c0 + d->c1), "conv K must equal 9*(c0+c1)");
+        const int ks = d->ksize == 1 ? 1 : 3;
+        SDOD_REQUIRE(d->ksize == 0 || d->ksize == 1 || d->ksize == 3, "conv kernel size must be 1 or 3");
+        SDOD_REQUIRE(d->K == ks * ks * (d->c0 + d->c1), "conv K must equal ksize^2*(c0+c1)");
+        p.ksize = ks;
         SDOD_REQUIRE(!(d->upsample && d->stride != 1), "upsample implies stride 1");
         p.h_in = d->h_in; p.w_in = d->w_in; p.c0 = d->c0; p.c1 = d->c1;
         p.stride = d->stride; p.ups = d->upsample ? 1 : 0;
         const int hup = d->h_in << p.ups, wup = d->w_in << p.ups;
-        p.h_out = (hup + 2 - 3) / d->stride + 1;
-        p.w_out = (wup + 2 - 3) / d->stride + 1;
+        p.h_out = (hup + 2 * (ks / 2) - ks) / d->stride + 1;
+        p.w_out = (wup + 2 * (ks / 2) - ks) / d->stride + 1;
         SDOD_REQUIRE(d->M == d->n_img * p.h_out * p.w_out, "conv M must equal n_img*h_out*w_out");
     } else {
         SDOD_REQUIRE(d->a_mode == SDOD_A_ROWS, "unknown a_mode");
         SDOD_REQUIRE(d->lda >= d->K && d->lda % 8 == 0, "lda must be >= K and a multiple of 8");
-        p.c0 = d->K; p.c1 = 0; p.h_in = p.w_in = p.h_out = p.w_out = 1; p.stride = 1;
+        p.c0 = d->K; p.c1 = 0; p.h_in = p.w_in = p.h_out = p.w_out = 1; p.stride = 1; p.ksize = 1;
     }
     const Plan pl = make_plan(d);
     p.splits = pl.splits;

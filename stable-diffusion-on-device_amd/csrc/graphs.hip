@@ -1,0 +1,445 @@
+// graphs.hip -- launch-list builders for the four graphs of the txt2img path: UNet eps-model, VAE decoder,
+// CLIP text encoder, time-embedding MLP.  They stand in for the serialized QNN graphs the reference loads
+// (context.cpp:105: "unet.serialized", "text_encoder.serialized", "vae_decoder.serialized", "temb"); the
+// block structure follows the op names visible in the reference's own profiler table
+// (analyze_results.py:20-93: in_layers / emb_layers / out_layers / skip_connection, norm / proj_in /
+// transformer_blocks.0.{norm1-3, attn1, attn2, ff.net.0.proj, ff.net.2} / proj_out) and the public SD v1.x
+// architecture.  Parameter names are the CompVis-ldm / HF-CLIP state-dict keys.
+//
+// Fusions decided here (all are reads/writes removed from HBM, the UNet sits at the roofline ridge):
+//   * SiLU into every ResBlock GroupNorm; the skip-connection channel concat into the GroupNorm reads and
+//     into the conv gathers (no concat tensor); nearest-2x upsampling into the conv gather;
+//   * conv bias + time-embedding broadcast + residual into the conv epilogue;
+//   * to_q/to_k/to_v as ONE GEMM (weights contiguous in the arena); all 22 ResBlock time-embedding
+//     projections as ONE GEMM per UNet evaluation; attention output / FF output residuals in the GEMM epilogue;
+//   * z/0.18215 and post_quant_conv into the latent layout change.
+#include "engine.h"
+
+namespace sdod {
+
+static void check_rc2(int rc) {
+    if (rc != 0) throw Error(rc, get_last_error());
+}
+
+const char* Graph::group_base(const std::string& group) const {
+    auto it = gindex_.find(group);
+    if (it == gindex_.end()) throw Error(INTERNAL_ERROR, "unknown parameter group " + group);
+    return params_[groups_[it->second].front()].dev;
+}
+
+// ------------------------------------------------------------------------------------------------ UNet
+Act Graph::res_block(const std::string& pfx, const Act& x, const Act* x2, int cout, const f16* emb_all, int emb_ld, int& emb_off) {
+    const int cin = x.c + (x2 ? x2->c : 0);
+    const int emb_ch = 4 * cfg_.model_channels;
+    const int n1w = P(pfx + ".in_layers.0.weight", {cin}, PK_VEC), n1b = P(pfx + ".in_layers.0.bias", {cin}, PK_VEC);
+    const int c1w = P(pfx + ".in_layers.2.weight", {cout, cin, 3, 3}, PK_CONV3), c1b = P(pfx + ".in_layers.2.bias", {cout}, PK_VEC);
+    P(pfx + ".emb_layers.1.weight", {cout, emb_ch}, PK_LINEAR, "emb_w");
+    P(pfx + ".emb_layers.1.bias", {cout}, PK_VEC, "emb_b");
+    const int n2w = P(pfx + ".out_layers.0.weight", {cout}, PK_VEC), n2b = P(pfx + ".out_layers.0.bias", {cout}, PK_VEC);
+    const int c2w = P(pfx + ".out_layers.3.weight", {cout, cout, 3, 3}, PK_CONV3), c2b = P(pfx + ".out_layers.3.bias", {cout}, PK_VEC);
+    int skw = -1, skb = -1;
+    if (cin != cout) {
+        skw = P(pfx + ".skip_connection.weight", {cout, cin, 1, 1}, PK_CONV1);
+        skb = P(pfx + ".skip_connection.bias", {cout}, PK_VEC);
+    }
+    const int my_off = emb_off;
+    emb_off += cout;
+
+    Act g1 = group_norm(x, x2, n1w, n1b, 1e-5f, true);
+    GemmOpt o1;
+    o1.bias = c1b;
+    o1.row_bias = emb_all ? emb_all + my_off : nullptr;
+    o1.ld_row_bias = emb_ld;
+    o1.rows_per_img = x.h * x.w;
+    Act h = conv(g1, nullptr, c1w, cout, 3, 1, false, o1);
+    release(g1);
+    Act g2 = group_norm(h, nullptr, n2w, n2b, 1e-5f, true);
+    release(h);
+    Act s;
+    GemmOpt o2;
+    o2.bias = c2b;
+    if (cin != cout) {
+        GemmOpt os;
+        os.bias = skb;
+        s = conv(x, x2, skw, cout, 1, 1, false, os);
+        o2.residual = s.p;
+    } else {
+        if (x2) throw Error(INTERNAL_ERROR, "identity skip with a concatenated input");
+        o2.residual = x.p;
+    }
+    Act out = conv(g2, nullptr, c2w, cout, 3, 1, false, o2);
+    release(g2);
+    if (s.p) release(s);
+    return out;
+}
+
+Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& ctx) {
+    const int C = x.c, cd = ctx.c;
+    const int heads = cfg_.num_heads > 0 ? cfg_.num_heads : C / cfg_.head_dim;
+    const int d = C / heads;
+    const int rows = x.rows(), L = x.h * x.w, B = x.n;
+    const std::string tb = pfx + ".transformer_blocks.0";
+    const int nw = P(pfx + ".norm.weight", {C}, PK_VEC), nb = P(pfx + ".norm.bias", {C}, PK_VEC);
+    const int piw = P(pfx + ".proj_in.weight", {C, C, 1, 1}, PK_CONV1), pib = P(pfx + ".proj_in.bias", {C}, PK_VEC);
+    const int l1w = P(tb + ".norm1.weight", {C}, PK_VEC), l1b = P(tb + ".norm1.bias", {C}, PK_VEC);
+    const std::string gq = tb + ".attn1.qkv";
+    P(tb + ".attn1.to_q.weight", {C, C}, PK_LINEAR, gq);
+    P(tb + ".attn1.to_k.weight", {C, C}, PK_LINEAR, gq);
+    P(tb + ".attn1.to_v.weight", {C, C}, PK_LINEAR, gq);
+    const int o1w = P(tb + ".attn1.to_out.0.weight", {C, C}, PK_LINEAR), o1b = P(tb + ".attn1.to_out.0.bias", {C}, PK_VEC);
+    const int l2w = P(tb + ".norm2.weight", {C}, PK_VEC), l2b = P(tb + ".norm2.bias", {C}, PK_VEC);
+    const int q2w = P(tb + ".attn2.to_q.weight", {C, C}, PK_LINEAR);
+    const std::string gkv = tb + ".attn2.kv";
+    P(tb + ".attn2.to_k.weight", {C, cd}, PK_LINEAR, gkv);
+    P(tb + ".attn2.to_v.weight", {C, cd}, PK_LINEAR, gkv);
+    const int o2w = P(tb + ".attn2.to_out.0.weight", {C, C}, PK_LINEAR), o2b = P(tb + ".attn2.to_out.0.bias", {C}, PK_VEC);
+    const int l3w = P(tb + ".norm3.weight", {C}, PK_VEC), l3b = P(tb + ".norm3.bias", {C}, PK_VEC);
+    const int f1w = P(tb + ".ff.net.0.proj.weight", {8 * C, C}, PK_LINEAR), f1b = P(tb + ".ff.net.0.proj.bias", {8 * C}, PK_VEC);
+    const int f2w = P(tb + ".ff.net.2.weight", {C, 4 * C}, PK_LINEAR), f2b = P(tb + ".ff.net.2.bias", {C}, PK_VEC);
+    const int pow_ = P(pfx + ".proj_out.weight", {C, C, 1, 1}, PK_CONV1), pob = P(pfx + ".proj_out.bias", {C}, PK_VEC);
+    if (mode_ == DECLARE) return act(x.n, x.h, x.w, C);
+
+    Act g = group_norm(x, nullptr, nw, nb, 1e-6f, false);
+    Act t0 = act(B, 1, L, C);
+    { GemmOpt o; o.bias = pib; linear(g.p, rows, C, piw, C, t0.p, o); }
+    release(g);
+    // self-attention
+    Act n1 = layer_norm(t0, l1w, l1b, 1e-5f);
+    f16* qkv = alloc((size_t)rows * 3 * C);
+    linear_raw(n1.p, rows, C, reinterpret_cast<const f16*>(group_base(gq)), C, 3 * C, qkv, GemmOpt{});
+    release(n1);
+    f16* a1 = alloc((size_t)rows * C);
+    attention(qkv, qkv + C, qkv + 2 * C, a1, B, heads, L, L, d, 3 * C, 3 * C, 3 * C, C, false);
+    release(qkv);
+    Act t1 = act(B, 1, L, C);
+    { GemmOpt o; o.bias = o1b; o.residual = t0.p; linear(a1, rows, C, o1w, C, t1.p, o); }
+    release(a1); release(t0);
+    // cross-attention on the text context
+    Act n2 = layer_norm(t1, l2w, l2b, 1e-5f);
+    f16* q2 = alloc((size_t)rows * C);
+    linear(n2.p, rows, C, q2w, C, q2, GemmOpt{});
+    release(n2);
+    const int crow = ctx.rows(), Lk = ctx.w;
+    f16* kv = alloc((size_t)crow * 2 * C);
+    linear_raw(ctx.p, crow, cd, reinterpret_cast<const f16*>(group_base(gkv)), cd, 2 * C, kv, GemmOpt{});
+    f16* a2 = alloc((size_t)rows * C);
+    attention(q2, kv, kv + C, a2, B, heads, L, Lk, d, C, 2 * C, 2 * C, C, false);
+    release(q2); release(kv);
+    Act t2 = act(B, 1, L, C);
+    { GemmOpt o; o.bias = o2b; o.residual = t1.p; linear(a2, rows, C, o2w, C, t2.p, o); }
+    release(a2); release(t1);
+    // GEGLU feed-forward
+    Act n3 = layer_norm(t2, l3w, l3b, 1e-5f);
+    f16* ff = alloc((size_t)rows * 8 * C);
+    { GemmOpt o; o.bias = f1b; linear(n3.p, rows, C, f1w, 8 * C, ff, o); }
+    release(n3);
+    f16* gg = alloc((size_t)rows * 4 * C);
+    emit([=](hipStream_t st) { check_rc2(sdod_geglu_f16(ff, gg, rows, 4 * C, st)); });
+    release(ff);
+    Act t3 = act(B, 1, L, C);
+    { GemmOpt o; o.bias = f2b; o.residual = t2.p; linear(gg, rows, 4 * C, f2w, C, t3.p, o); }
+    release(gg); release(t2);
+    Act out = act(x.n, x.h, x.w, C);
+    { GemmOpt o; o.bias = pob; o.residual = x.p; linear(t3.p, rows, C, pow_, C, out.p, o); }
+    release(t3);
+    return out;
+}
+
+void Graph::build_unet() {
+    const int B = batch_, H = cfg_.latent_h, Wd = cfg_.latent_w, LC = cfg_.latent_channels;
+    const int MC = cfg_.model_channels, EC = 4 * MC, cd = cfg_.context_dim, CL = cfg_.context_len;
+    SDOD_REQUIRE(LC * 9 <= 64, "latent_channels too large for the small-Cin path");
+    const int mult[4] = {1, 2, 4, 4};
+
+    float* x_in = (float*)io_alloc(inputs_, (size_t)B * LC * H * Wd * sizeof(float));
+    f16* temb_in = (f16*)io_alloc(inputs_, (size_t)B * EC * sizeof(f16));
+    f16* ctx_in = (f16*)io_alloc(inputs_, (size_t)B * CL * cd * sizeof(f16));
+    f16* e_out = (f16*)io_alloc(outputs_, (size_t)B * H * Wd * LC * sizeof(f16));
+    Act ctx;
+    ctx.p = ctx_in; ctx.n = B; ctx.h = 1; ctx.w = CL; ctx.c = cd;
+
+    // time embedding -> all ResBlock projections in one GEMM
+    f16* st_emb = alloc((size_t)B * EC);
+    emit([=](hipStream_t st) { check_rc2(sdod_act_f16(temb_in, st_emb, (size_t)B * EC, SDOD_ACT_SILU, st)); });
+    const int emb_ld = emb_total_;
+    f16* emb_all = nullptr;
+    if (mode_ != DECLARE) {
+        emb_all = alloc((size_t)B * emb_ld);
+        GemmOpt o;
+        o.bias_raw = reinterpret_cast<const float*>(group_base("emb_b"));
+        linear_raw(st_emb, B, EC, reinterpret_cast<const f16*>(group_base("emb_w")), EC, emb_ld, emb_all, o);
+    }
+    int emb_off = 0;
+
+    // input conv (Cin = 4): im2col to K = 64, then the GEMM
+    const int ciw = P("input_blocks.0.0.weight", {MC, LC, 3, 3}, PK_CONV3_SMALL), cib = P("input_blocks.0.0.bias", {MC}, PK_VEC);
+    Act x_nhwc = act(B, H, Wd, LC);
+    emit([=](hipStream_t st) { check_rc2(sdod_latent_prep_f16(x_in, nullptr, nullptr, x_nhwc.p, B, LC, H * Wd, 1.0f, st)); });
+    f16* cols = alloc((size_t)B * H * Wd * 64);
+    emit([=](hipStream_t st) { check_rc2(sdod_im2col3x3_small_f16(x_nhwc.p, cols, B, H, Wd, LC, 64, st)); });
+    Act h = act(B, H, Wd, MC);
+    { GemmOpt o; o.bias = cib; linear(cols, B * H * Wd, 64, ciw, MC, h.p, o); }
+    release(cols); release(x_nhwc);
+
+    std::vector<Act> hs;
+    hs.push_back(h);
+    int ch = MC, ds = 1, idx = 1;
+    for (int level = 0; level < 4; ++level) {
+        for (int i = 0; i < 2; ++i) {
+            const std::string pfx = "input_blocks." + std::to_string(idx++);
+            Act r = res_block(pfx + ".0", h, nullptr, mult[level] * MC, emb_all, emb_ld, emb_off);
+            ch = mult[level] * MC;
+            if (ds <= 4) {
+                Act t = spatial_transformer(pfx + ".1", r, ctx);
+                release(r);
+                r = t;
+            }
+            h = r;
+            hs.push_back(h);
+        }
+        if (level != 3) {
+            const std::string pfx = "input_blocks." + std::to_string(idx++) + ".0.op";
+            const int w = P(pfx + ".weight", {ch, ch, 3, 3}, PK_CONV3), b = P(pfx + ".bias", {ch}, PK_VEC);
+            GemmOpt o; o.bias = b;
+            h = conv(h, nullptr, w, ch, 3, 2, false, o);
+            hs.push_back(h);
+            ds *= 2;
+        }
+    }
+    // middle (h is the last skip and stays on the stack until popped)
+    {
+        Act r1 = res_block("middle_block.0", h, nullptr, ch, emb_all, emb_ld, emb_off);
+        Act t = spatial_transformer("middle_block.1", r1, ctx);
+        release(r1);
+        Act r2 = res_block("middle_block.2", t, nullptr, ch, emb_all, emb_ld, emb_off);
+        release(t);
+        h = r2;
+    }
+    int oidx = 0;
+    for (int level = 3; level >= 0; --level) {
+        for (int i = 0; i < 3; ++i) {
+            const std::string pfx = "output_blocks." + std::to_string(oidx++);
+            Act skip = hs.back();
+            hs.pop_back();
+            Act r = res_block(pfx + ".0", h, &skip, mult[level] * MC, emb_all, emb_ld, emb_off);
+            release(h); release(skip);
+            ch = mult[level] * MC;
+            int sub = 1;
+            if (ds <= 4) {
+                Act t = spatial_transformer(pfx + "." + std::to_string(sub++), r, ctx);
+                release(r);
+                r = t;
+            }
+            if (level != 0 && i == 2) {
+                const std::string up = pfx + "." + std::to_string(sub) + ".conv";
+                const int w = P(up + ".weight", {ch, ch, 3, 3}, PK_CONV3), b = P(up + ".bias", {ch}, PK_VEC);
+                GemmOpt o; o.bias = b;
+                Act u = conv(r, nullptr, w, ch, 3, 1, true, o);
+                release(r);
+                r = u;
+                ds /= 2;
+            }
+            h = r;
+        }
+    }
+    const int ow = P("out.0.weight", {ch}, PK_VEC), ob = P("out.0.bias", {ch}, PK_VEC);
+    const int cw = P("out.2.weight", {LC, ch, 3, 3}, PK_CONV3), cb = P("out.2.bias", {LC}, PK_VEC);
+    Act g = group_norm(h, nullptr, ow, ob, 1e-5f, true);
+    release(h);
+    { GemmOpt o; o.bias = cb; o.out = e_out; conv(g, nullptr, cw, LC, 3, 1, false, o); }
+    release(g);
+    release(st_emb);
+    if (emb_all) release(emb_all);
+    if (mode_ == DECLARE) emb_total_ = emb_off;
+    else if (emb_off != emb_total_) throw Error(INTERNAL_ERROR, "time-embedding projection bookkeeping mismatch");
+}
+
+// ------------------------------------------------------------------------------------------------ temb
+void Graph::build_temb() {
+    const int B = batch_, MC = cfg_.model_channels, EC = 4 * MC;
+    float* t_in = (float*)io_alloc(inputs_, (size_t)B * sizeof(float));
+    f16* out = (f16*)io_alloc(outputs_, (size_t)B * EC * sizeof(f16));
+    const int w0 = P("time_embed.0.weight", {EC, MC}, PK_LINEAR), b0 = P("time_embed.0.bias", {EC}, PK_VEC);
+    const int w2 = P("time_embed.2.weight", {EC, EC}, PK_LINEAR), b2 = P("time_embed.2.bias", {EC}, PK_VEC);
+    f16* feat = alloc((size_t)B * MC);
+    emit([=](hipStream_t st) { check_rc2(sdod_timestep_features_f16(t_in, feat, B, MC, st)); });
+    f16* hmid = alloc((size_t)B * EC);
+    { GemmOpt o; o.bias = b0; o.act = SDOD_ACT_SILU; linear(feat, B, MC, w0, EC, hmid, o); }
+    { GemmOpt o; o.bias = b2; linear(hmid, B, EC, w2, EC, out, o); }
+    release(feat); release(hmid);
+}
+
+// ------------------------------------------------------------------------------------------------ VAE
+Act Graph::vae_res_block(const std::string& pfx, const Act& x, int cout) {
+    const int cin = x.c;
+    const int n1w = P(pfx + ".norm1.weight", {cin}, PK_VEC), n1b = P(pfx + ".norm1.bias", {cin}, PK_VEC);
+    const int c1w = P(pfx + ".conv1.weight", {cout, cin, 3, 3}, PK_CONV3), c1b = P(pfx + ".conv1.bias", {cout}, PK_VEC);
+    const int n2w = P(pfx + ".norm2.weight", {cout}, PK_VEC), n2b = P(pfx + ".norm2.bias", {cout}, PK_VEC);
+    const int c2w = P(pfx + ".conv2.weight", {cout, cout, 3, 3}, PK_CONV3), c2b = P(pfx + ".conv2.bias", {cout}, PK_VEC);
+    int skw = -1, skb = -1;
+    if (cin != cout) {
+        skw = P(pfx + ".nin_shortcut.weight", {cout, cin, 1, 1}, PK_CONV1);
+        skb = P(pfx + ".nin_shortcut.bias", {cout}, PK_VEC);
+    }
+    Act g1 = group_norm(x, nullptr, n1w, n1b, 1e-6f, true);
+    GemmOpt o1; o1.bias = c1b;
+    Act h = conv(g1, nullptr, c1w, cout, 3, 1, false, o1);
+    release(g1);
+    Act g2 = group_norm(h, nullptr, n2w, n2b, 1e-6f, true);
+    release(h);
+    Act s;
+    GemmOpt o2; o2.bias = c2b;
+    if (cin != cout) {
+        s = act(x.n, x.h, x.w, cout);
+        GemmOpt os; os.bias = skb;
+        linear(x.p, x.rows(), cin, skw, cout, s.p, os);
+        o2.residual = s.p;
+    } else {
+        o2.residual = x.p;
+    }
+    Act out = conv(g2, nullptr, c2w, cout, 3, 1, false, o2);
+    release(g2);
+    if (s.p) release(s);
+    return out;
+}
+
+Act Graph::vae_attn_block(const std::string& pfx, const Act& x) {
+    const int C = x.c, L = x.h * x.w, B = x.n, rows = x.rows();
+    const int nw = P(pfx + ".norm.weight", {C}, PK_VEC), nb = P(pfx + ".norm.bias", {C}, PK_VEC);
+    const std::string gw = pfx + ".qk_w", gb = pfx + ".qk_b";
+    P(pfx + ".q.weight", {C, C, 1, 1}, PK_CONV1, gw);
+    P(pfx + ".k.weight", {C, C, 1, 1}, PK_CONV1, gw);
+    P(pfx + ".q.bias", {C}, PK_VEC, gb);
+    P(pfx + ".k.bias", {C}, PK_VEC, gb);
+    const int vw = P(pfx + ".v.weight", {C, C, 1, 1}, PK_CONV1), vb = P(pfx + ".v.bias", {C}, PK_VEC);
+    const int pw = P(pfx + ".proj_out.weight", {C, C, 1, 1}, PK_CONV1), pb = P(pfx + ".proj_out.bias", {C}, PK_VEC);
+    if (mode_ == DECLARE) return act(x.n, x.h, x.w, C);
+    SDOD_REQUIRE(L % 64 == 0 && L <= 8192, "VAE attention needs H*W % 64 == 0 and <= 8192");
+
+    Act g = group_norm(x, nullptr, nw, nb, 1e-6f, false);
+    f16* qk = alloc((size_t)rows * 2 * C);
+    { GemmOpt o; o.bias_raw = reinterpret_cast<const float*>(group_base(gb));
+      linear_raw(g.p, rows, C, reinterpret_cast<const f16*>(group_base(gw)), C, 2 * C, qk, o); }
+    f16* att = alloc((size_t)rows * C);
+    for (int b = 0; b < B; ++b) {
+        const f16* gb_ = g.p + (size_t)b * L * C;
+        f16* vt = alloc((size_t)C * L); // V^T [C][L] = Wv . g_b^T + bv   (bias indexed by the output row)
+        { GemmOpt o; o.bias = vb; o.bias_on_m = true;
+          linear_raw(W<f16>(vw), C, C, gb_, C, L, vt, o); }
+        f16* sc = alloc((size_t)L * L);  // scores, softmaxed in place
+        { GemmOpt o; o.alpha = 1.0f / sqrtf((float)C); o.lda = 2 * C;
+          linear_raw(qk + (size_t)b * L * 2 * C, L, C, qk + (size_t)b * L * 2 * C + C, 2 * C, L, sc, o); }
+        emit([=](hipStream_t st) { check_rc2(sdod_softmax_rows_f16(sc, sc, L, L, st)); });
+        linear_raw(sc, L, L, vt, L, C, att + (size_t)b * L * C, GemmOpt{});
+        release(sc); release(vt);
+    }
+    release(qk); release(g);
+    Act out = act(x.n, x.h, x.w, C);
+    { GemmOpt o; o.bias = pb; o.residual = x.p; linear(att, rows, C, pw, C, out.p, o); }
+    release(att);
+    return out;
+}
+
+void Graph::build_vae() {
+    const int B = batch_, H = cfg_.latent_h, Wd = cfg_.latent_w, LC = cfg_.latent_channels, VC = cfg_.vae_channels;
+    SDOD_REQUIRE(LC * 9 <= 64, "latent_channels too large for the small-Cin path");
+    const int mult[4] = {1, 2, 4, 4};
+    float* z_in = (float*)io_alloc(inputs_, (size_t)B * LC * H * Wd * sizeof(float));
+    f16* img_out = (f16*)io_alloc(outputs_, (size_t)B * (8 * H) * (8 * Wd) * 3 * sizeof(f16));
+
+    const int pqw = P("post_quant_conv.weight", {LC, LC, 1, 1}, PK_MAT_F32), pqb = P("post_quant_conv.bias", {LC}, PK_VEC);
+    Act zl = act(B, H, Wd, LC);
+    {
+        const float* wq = W<float>(pqw); const float* bq = W<float>(pqb);
+        emit([=](hipStream_t st) { check_rc2(sdod_latent_prep_f16(z_in, wq, bq, zl.p, B, LC, H * Wd, 1.0f / 0.18215f, st)); });
+    }
+    int ch = VC * mult[3];
+    const int ciw = P("decoder.conv_in.weight", {ch, LC, 3, 3}, PK_CONV3_SMALL), cib = P("decoder.conv_in.bias", {ch}, PK_VEC);
+    f16* cols = alloc((size_t)B * H * Wd * 64);
+    emit([=](hipStream_t st) { check_rc2(sdod_im2col3x3_small_f16(zl.p, cols, B, H, Wd, LC, 64, st)); });
+    Act h = act(B, H, Wd, ch);
+    { GemmOpt o; o.bias = cib; linear(cols, B * H * Wd, 64, ciw, ch, h.p, o); }
+    release(cols); release(zl);
+
+    { Act r = vae_res_block("decoder.mid.block_1", h, ch); release(h); h = r; }
+    { Act r = vae_attn_block("decoder.mid.attn_1", h); release(h); h = r; }
+    { Act r = vae_res_block("decoder.mid.block_2", h, ch); release(h); h = r; }
+    for (int level = 3; level >= 0; --level) {
+        const int cout = VC * mult[level];
+        for (int i = 0; i < 3; ++i) {
+            Act r = vae_res_block("decoder.up." + std::to_string(level) + ".block." + std::to_string(i), h, cout);
+            release(h);
+            h = r;
+        }
+        ch = cout;
+        if (level != 0) {
+            const std::string up = "decoder.up." + std::to_string(level) + ".upsample.conv";
+            const int w = P(up + ".weight", {ch, ch, 3, 3}, PK_CONV3), b = P(up + ".bias", {ch}, PK_VEC);
+            GemmOpt o; o.bias = b;
+            Act u = conv(h, nullptr, w, ch, 3, 1, true, o);
+            release(h);
+            h = u;
+        }
+    }
+    const int nw = P("decoder.norm_out.weight", {ch}, PK_VEC), nb = P("decoder.norm_out.bias", {ch}, PK_VEC);
+    const int cw = P("decoder.conv_out.weight", {3, ch, 3, 3}, PK_CONV3), cb = P("decoder.conv_out.bias", {3}, PK_VEC);
+    Act g = group_norm(h, nullptr, nw, nb, 1e-6f, true);
+    release(h);
+    { GemmOpt o; o.bias = cb; o.out = img_out; conv(g, nullptr, cw, 3, 3, 1, false, o); }
+    release(g);
+}
+
+// ------------------------------------------------------------------------------------------------ CLIP
+void Graph::build_clip() {
+    const int B = batch_, L = cfg_.context_len, D = cfg_.context_dim, heads = cfg_.text_heads, NL = cfg_.text_layers;
+    const int rows = B * L, inter = 4 * D;
+    SDOD_REQUIRE(D % heads == 0 && D / heads == 64, "text encoder head dim must be 64");
+    int32_t* ids = (int32_t*)io_alloc(inputs_, (size_t)rows * sizeof(int32_t));
+    f16* out = (f16*)io_alloc(outputs_, (size_t)rows * D * sizeof(f16));
+    const int te = P("text_model.embeddings.token_embedding.weight", {cfg_.vocab_size, D}, PK_EMBED);
+    const int pe = P("text_model.embeddings.position_embedding.weight", {L, D}, PK_EMBED);
+    Act x = act(B, 1, L, D);
+    {
+        const f16* tp = W<f16>(te); const f16* pp = W<f16>(pe);
+        emit([=](hipStream_t st) { check_rc2(sdod_embedding_f16(ids, tp, pp, x.p, rows, L, D, st)); });
+    }
+    for (int l = 0; l < NL; ++l) {
+        const std::string pfx = "text_model.encoder.layers." + std::to_string(l);
+        const int l1w = P(pfx + ".layer_norm1.weight", {D}, PK_VEC), l1b = P(pfx + ".layer_norm1.bias", {D}, PK_VEC);
+        const std::string gw = pfx + ".qkv_w", gb = pfx + ".qkv_b";
+        for (const char* n : {"q_proj", "k_proj", "v_proj"}) P(pfx + ".self_attn." + n + ".weight", {D, D}, PK_LINEAR, gw);
+        for (const char* n : {"q_proj", "k_proj", "v_proj"}) P(pfx + ".self_attn." + n + ".bias", {D}, PK_VEC, gb);
+        const int ow = P(pfx + ".self_attn.out_proj.weight", {D, D}, PK_LINEAR), ob = P(pfx + ".self_attn.out_proj.bias", {D}, PK_VEC);
+        const int l2w = P(pfx + ".layer_norm2.weight", {D}, PK_VEC), l2b = P(pfx + ".layer_norm2.bias", {D}, PK_VEC);
+        const int f1w = P(pfx + ".mlp.fc1.weight", {inter, D}, PK_LINEAR), f1b = P(pfx + ".mlp.fc1.bias", {inter}, PK_VEC);
+        const int f2w = P(pfx + ".mlp.fc2.weight", {D, inter}, PK_LINEAR), f2b = P(pfx + ".mlp.fc2.bias", {D}, PK_VEC);
+        if (mode_ == DECLARE) continue;
+        Act n1 = layer_norm(x, l1w, l1b, 1e-5f);
+        f16* qkv = alloc((size_t)rows * 3 * D);
+        { GemmOpt o; o.bias_raw = reinterpret_cast<const float*>(group_base(gb));
+          linear_raw(n1.p, rows, D, reinterpret_cast<const f16*>(group_base(gw)), D, 3 * D, qkv, o); }
+        release(n1);
+        f16* a = alloc((size_t)rows * D);
+        attention(qkv, qkv + D, qkv + 2 * D, a, B, heads, L, L, D / heads, 3 * D, 3 * D, 3 * D, D, true);
+        release(qkv);
+        Act x1 = act(B, 1, L, D);
+        { GemmOpt o; o.bias = ob; o.residual = x.p; linear(a, rows, D, ow, D, x1.p, o); }
+        release(a); release(x);
+        Act n2 = layer_norm(x1, l2w, l2b, 1e-5f);
+        f16* f = alloc((size_t)rows * inter);
+        { GemmOpt o; o.bias = f1b; o.act = SDOD_ACT_QUICK_GELU; linear(n2.p, rows, D, f1w, inter, f, o); }
+        release(n2);
+        Act x2 = act(B, 1, L, D);
+        { GemmOpt o; o.bias = f2b; o.residual = x1.p; linear(f, rows, inter, f2w, D, x2.p, o); }
+        release(f); release(x1);
+        x = x2;
+    }
+    const int fw = P("text_model.final_layer_norm.weight", {D}, PK_VEC), fb = P("text_model.final_layer_norm.bias", {D}, PK_VEC);
+    if (mode_ == REAL) {
+        const f16* xp = x.p; const float* wp = W<float>(fw); const float* bp = W<float>(fb);
+        ops_.push_back([=](hipStream_t st) { check_rc2(sdod_layer_norm_f16(xp, out, wp, bp, rows, D, 1e-5f, st)); });
+    }
+    release(x);
+}
+
+} // namespace sdod

@@ -30,7 +30,7 @@ class SdodError(RuntimeError):
 
 
 def hip():
-    lib = load('libsdod_hip.so')
+    lib = load('libsdod.so')
     if not getattr(lib, '_sdod_typed', False):
         _declare(lib)
         lib._sdod_typed = True
@@ -49,7 +49,7 @@ class GemmDesc(ctypes.Structure):
         ('lda', c_int), ('ldw', c_int), ('ldo', c_int), ('ldr', c_int),
         ('a_mode', c_int),
         ('n_img', c_int), ('h_in', c_int), ('w_in', c_int), ('c0', c_int), ('c1', c_int),
-        ('stride', c_int), ('upsample', c_int), ('rows_per_img', c_int),
+        ('stride', c_int), ('upsample', c_int), ('ksize', c_int), ('rows_per_img', c_int), ('ld_row_bias', c_int),
         ('act', c_int), ('alpha', c_float), ('bias_on_m', c_int), ('split_k', c_int), ('tile', c_int),
     ]
 
@@ -71,6 +71,7 @@ def _declare(lib):
         'sdod_im2col3x3_small_f16': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
         'sdod_nchw_f32_to_nhwc_f16': (c_int, [P, P, c_int, c_int, c_int, c_float, P]),
         'sdod_nhwc_f16_to_nchw_f32': (c_int, [P, P, c_int, c_int, c_int, P]),
+        'sdod_latent_prep_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, P]),
         'sdod_embedding_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
         'sdod_timestep_features_f16': (c_int, [P, P, c_int, c_int, P]),
         'sdod_cfg_combine': (c_int, [P, P, c_int, c_int, c_int, c_float, c_int, c_int, P]),
@@ -91,7 +92,7 @@ HIP_SYMBOLS = [
     'sdod_gemm_f16', 'sdod_gemm_workspace_bytes', 'sdod_group_norm_workspace_bytes', 'sdod_group_norm_nhwc',
     'sdod_layer_norm_f16', 'sdod_attention_f16', 'sdod_softmax_rows_f16', 'sdod_geglu_f16', 'sdod_act_f16',
     'sdod_add_f16', 'sdod_concat_channels_f16', 'sdod_im2col3x3_small_f16', 'sdod_nchw_f32_to_nhwc_f16',
-    'sdod_nhwc_f16_to_nchw_f32', 'sdod_embedding_f16', 'sdod_timestep_features_f16', 'sdod_cfg_combine',
+    'sdod_nhwc_f16_to_nchw_f32', 'sdod_latent_prep_f16', 'sdod_embedding_f16', 'sdod_timestep_features_f16', 'sdod_cfg_combine',
     'sdod_dpm_update', 'sdod_ddim_step_f32', 'sdod_lincomb4_f32', 'sdod_image_to_u8', 'sdod_hip_last_error',
     'sdod_hip_device_info',
 ]

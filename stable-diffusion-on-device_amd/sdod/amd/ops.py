@@ -1,7 +1,7 @@
 """Thin torch-tensor wrappers over the kernel-level C ABI (include/sdod_hip.h).
 
 torch supplies device memory and the current stream only; every computation below is a call into
-lib/libsdod_hip.so.  Activations are NHWC fp16; a torch NCHW tensor in channels_last memory format
+lib/libsdod.so.  Activations are NHWC fp16; a torch NCHW tensor in channels_last memory format
 IS that layout, so the conversions are views."""
 import ctypes
 
@@ -68,8 +68,10 @@ def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=N
             assert a2.shape[:3] == a.shape[:3]
             c1 = a2.shape[3]
         stride = int(conv.get('stride', 1)); ups = 1 if conv.get('upsample', False) else 0
+        ks = int(conv.get('ksize', 3))
         hup, wup = h << ups, wd << ups
-        ho, wo = (hup + 2 - 3) // stride + 1, (wup + 2 - 3) // stride + 1
+        ho, wo = (hup + 2 * (ks // 2) - ks) // stride + 1, (wup + 2 * (ks // 2) - ks) // stride + 1
+        d.ksize = ks
         m = n_img * ho * wo
         d.a_mode = 1
         d.n_img, d.h_in, d.w_in, d.c0, d.c1 = n_img, h, wd, c0, c1
@@ -87,7 +89,8 @@ def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=N
     if bias is not None:
         _req(bias, torch.float32, 'bias'); d.bias = _p(bias)
     if row_bias is not None:
-        _req(row_bias, torch.float32, 'row_bias'); d.row_bias = _p(row_bias); d.rows_per_img = rows_per_img
+        _req(row_bias, torch.float16, 'row_bias'); d.row_bias = _p(row_bias); d.rows_per_img = rows_per_img
+        d.ld_row_bias = row_bias.shape[-1]
     if residual is not None:
         _req(residual, torch.float16, 'residual'); assert residual.numel() == m * nout
         d.residual = _p(residual); d.ldr = nout

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 
 def _hip_group_norm(x, num_groups, weight, bias, eps, silu=False):
-    from .amd import ops  # raises loudly if lib/libsdod_hip.so is not built
+    from .amd import ops  # raises loudly if lib/libsdod.so is not built
     return ops.group_norm_nchw(x, num_groups, weight, bias, eps, silu)
 
 

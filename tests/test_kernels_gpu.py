@@ -1,4 +1,4 @@
-"""GPU parity tests of the individual gfx950 kernels, called through the C ABI (lib/libsdod_hip.so).
+"""GPU parity tests of the individual gfx950 kernels, called through the C ABI (lib/libsdod.so).
 
 Checker: plain PyTorch fp32 on the CPU of the same op on the same fp16-rounded inputs.
 Tolerances (stated, fp16 in/out with fp32 accumulation): rel-L2 <= 2e-3 per kernel,
@@ -69,8 +69,8 @@ def test_gemm_split_k(split):
     m, n, k = 128, 320, 2880
     a = rnd((m, k), 5); w = rnd((n, k), 6, k ** -0.5)
     bias = torch.randn(n, generator=torch.Generator().manual_seed(7))
-    rb = torch.randn(2, n, generator=torch.Generator().manual_seed(8))
-    ref = a.float() @ w.float().t() + bias + rb.repeat_interleave(64, 0)
+    rb = torch.randn(2, n, generator=torch.Generator().manual_seed(8)).half()
+    ref = a.float() @ w.float().t() + bias + rb.float().repeat_interleave(64, 0)
     d = dev()
     out = ops.gemm(a.to(d), w.to(d), bias.to(d), row_bias=rb.to(d), rows_per_img=64, split_k=split)
     check(out, ref, name=f'splitk {split}')
@@ -120,14 +120,27 @@ def test_conv3x3_concat_rowbias_residual():
     x0 = rnd((n, h, w, c0), 30); x1 = rnd((n, h, w, c1), 31)
     wt = rnd((cout, 9 * (c0 + c1)), 32, (9 * (c0 + c1)) ** -0.5)
     bias = torch.randn(cout, generator=torch.Generator().manual_seed(33))
-    rb = torch.randn(n, cout, generator=torch.Generator().manual_seed(34))
+    rb = torch.randn(n, cout, generator=torch.Generator().manual_seed(34)).half()
     res = rnd((n, h, w, cout), 35)
-    ref = conv_ref(torch.cat([x0, x1], -1), wt, bias) + rb[:, None, None, :]
+    ref = conv_ref(torch.cat([x0, x1], -1), wt, bias) + rb.float()[:, None, None, :]
     ref = ref.half().float() + res.float()
     d = dev()
     out = ops.gemm(x0.to(d), wt.to(d), bias.to(d), a2=x1.to(d), conv=dict(stride=1), row_bias=rb.to(d), rows_per_img=h * w,
                    residual=res.to(d))
     check(out, ref, name='conv concat')
+
+
+def test_conv1x1_two_sources():
+    """1x1 skip convolution of a ResBlock whose input is a channel concat (h, skip) -- no concat tensor in HBM."""
+    from sdod.amd import ops
+    n, h, w, c0, c1, cout = 2, 8, 8, 1280, 640, 1280
+    x0 = rnd((n, h, w, c0), 36); x1 = rnd((n, h, w, c1), 37)
+    wt = rnd((cout, c0 + c1), 38, (c0 + c1) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(39))
+    ref = torch.cat([x0, x1], -1).float() @ wt.float().t() + bias
+    d = dev()
+    out = ops.gemm(x0.to(d), wt.to(d), bias.to(d), a2=x1.to(d), conv=dict(stride=1, ksize=1))
+    check(out, ref, name='conv1x1 concat')
 
 
 def test_conv_small_cin_via_im2col():
