@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X txt2img hot path.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): SD v1.4, 512x512, 20-step PLMS,
+guidance 7.5: CLIP text encode (uncond + cond) -> 21 batched (uncond, cond) UNet evaluations with CFG + PLMS updates
+-> VAE decode -> uint8 HWC image.  One "step" = one such image per GPU (weak scaling: every rank generates its own
+image(s); rank 0 encodes the prompt and the conditioning is sent with ONE RCCL broadcast).  Synthetic seeded weights
+(no checkpoint exists offline), fixed token ids, injected x_T; all inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).  Extra blocks:
+  roofline     -- for the dominant kernel family of the UNet launch list: algorithmic FLOPs (or bytes) per launch
+                  divided by its average launch duration, measured in this process with HIP events on the launch stream
+  cpu_baseline -- the oracle (PyTorch-CPU fp32 restatement, kind "port") timed on the host cores on a bounded sample
+  parity       -- GPU fp16 vs CPU fp32 on the first guided UNet evaluation of this very run
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'stable-diffusion-on-device_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+METRIC = 'images/sec + per-UNet-step ms, SD v1.4 512x512 20-step PLMS, 1/2/4/8 MI355X'
+PEAK_TFLOPS_F16 = 2500.0   # dense fp16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+# "a photograph of an astronaut riding a horse" needs the CLIP vocabulary, which is absent offline: fixed ids
+IDS_COND = [49406, 320, 1125, 539, 550, 18376, 6765, 320, 4558] + [49407] * 68
+IDS_UNCOND = [49406] + [49407] * 76
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3, help='timed images per GPU')
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--images-per-gpu', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-hip-graph', action='store_true')
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from sdod.amd import engine as E, ops, weights as Wt
+    from sdod.amd.pipeline import Txt2Img, broadcast_conditioning, initial_latent
+
+    t_setup = time.time()
+    cfg = E.sd14_config(64, 64)
+    n = args.images_per_gpu
+    tables = {'unet': E.UNet(cfg, 2).param_table(), 'temb': E.Temb(cfg, 1).param_table(),
+              'vae': E.VaeDecoder(cfg, 1).param_table(), 'text': E.TextEncoder(cfg, 1).param_table()}
+    sds = {k: Wt.synthetic_state_dict(t, seed=1234 + i) for i, (k, t) in enumerate(tables.items())}
+    pipe = Txt2Img(state_dicts=sds, images_per_gpu=n, latent_hw=64, device=f'cuda:{local_rank}',
+                   use_hip_graph=not args.no_hip_graph)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if not want_cpu:
+        sds = None
+    setup_s = time.time() - t_setup
+
+    x_T = torch.cat([initial_latent(42, rank * n + i) for i in range(n)]).to(device)
+    ids_u, ids_c = np.asarray(IDS_UNCOND), np.asarray(IDS_COND)
+
+    def one_image():
+        if rank == 0:
+            ctx2 = pipe.encode_tokens(ids_u, ids_c)
+        else:
+            ctx2 = torch.empty(2, cfg.context_len, cfg.context_dim, dtype=torch.float16, device=device)
+        ctx2 = broadcast_conditioning(ctx2, 0)
+        z = pipe.sample_plms(ctx2, x_T, steps=20, guidance=7.5)
+        return pipe.decode(z, mode=1)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        img = one_image()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img = one_image()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert img.shape == (n, 512, 512, 3) and img.dtype == torch.uint8
+
+    # ---- per-UNet-step time (batched cond+uncond evaluation + CFG + sampler update), HIP-graph replay, same stream
+    ctx2 = pipe.encode_tokens(ids_u, ids_c) if rank == 0 else torch.zeros(2, 77, 768, dtype=torch.float16, device=device)
+    pipe._set_context(ctx2)
+    temb = pipe.time_embeddings(np.asarray([951.0], np.float32))
+    x = x_T.clone()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(2):
+        e = pipe._eps(x, temb[0], 7.5, 1)
+    reps = 10
+    ev0.record()
+    for _ in range(reps):
+        e = pipe._eps(x, temb[0], 7.5, 1)
+        ops.ddim_step(x.clone(), e, 0.5, 0.5, 0.5, 0.5)
+    ev1.record()
+    torch.cuda.synchronize()
+    unet_step_ms = ev0.elapsed_time(ev1) / reps
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel family: per-launch HIP events over the UNet launch list (eager, same stream)
+        table = pipe.unet.op_table()
+        ms = pipe.unet.profile(iters=3)
+        fam = {}
+        for (label, fl, by), t in zip(table, ms):
+            f = fam.setdefault(label, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            f['ms'] += t; f['flops'] += fl; f['bytes'] += by; f['launches'] += 1
+        dom = max(fam, key=lambda k: fam[k]['ms'])
+        d = fam[dom]
+        total_ms = sum(ms)
+        if d['flops'] > 0:
+            ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            roof = dict(bound='mfma', achieved=round(ach, 2), peak=PEAK_TFLOPS_F16, unit='TFLOP/s', frac=round(ach / PEAK_TFLOPS_F16, 4),
+                        traffic=None)
+        else:
+            ach = d['bytes'] / (d['ms'] * 1e-3) / 1e9
+            roof = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
+        roof.update(kernel=dom, launches_per_unet_eval=d['launches'], avg_launch_us=round(1e3 * d['ms'] / d['launches'], 2),
+                    share_of_unet_eval=round(d['ms'] / total_ms, 3), unet_eval_eager_ms=round(total_ms, 3),
+                    unet_eval_tflops=round(pipe.unet.stats()['flops'] / (unet_step_ms * 1e-3) / 1e12, 1),
+                    families={k: dict(ms=round(v['ms'], 3), launches=v['launches'],
+                                      tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1) if v['flops'] else None,
+                                      gbs=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['bytes'] else None)
+                              for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])})
+
+        value = args.steps * n * world / elapsed
+        out = {
+            'metric': METRIC, 'value': round(value, 4), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'config': {'workload': 'SD v1.4 txt2img 512x512, 20-step PLMS (21 UNet evals, batch 2 = cond+uncond per image), '
+                                   'CLIP encode + VAE decode + uint8, guidance 7.5',
+                       'images_per_gpu': n, 'global_batch': n * world, 'parallelism': f'dp{world} (image shards, 1 RCCL broadcast)',
+                       'hip_graph': not args.no_hip_graph},
+            'unet_step_ms': round(unet_step_ms, 3),
+            'roofline': roof,
+            'setup_s': round(setup_s, 1),
+        }
+
+        if want_cpu:
+            out.update(cpu_baseline_and_parity(pipe, sds, x_T, ctx2, e_gpu=pipe._eps(x_T, temb[0], 7.5, 1)))
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline_and_parity(pipe, sds, x_T, ctx2, e_gpu):
+    """The oracle (CPU fp32 restatement) on the host cores, bounded sample; also the in-run parity number."""
+    from oracle import sd_torch as S
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    with torch.device('meta'):
+        unet, vae, clip = S.UNetModel(), S.AutoencoderKLDecode(), S.ClipTextModel()
+    unet.load_state_dict({**sds['unet'], **sds['temb']}, assign=True)
+    vae.load_state_dict(sds['vae'], assign=True)
+    clip.load_state_dict(sds['text'], assign=True)
+    unet.eval(); vae.eval(); clip.eval()
+    c16 = ctx2.float().cpu()
+    x = x_T[:1].float().cpu()
+    t = torch.tensor([951, 951])
+    with torch.no_grad():
+        x2 = torch.cat([x, x]); c2 = torch.cat([c16[0:1], c16[1:2]])
+        t0 = time.perf_counter(); e = unet(x2, t, c2); warm = time.perf_counter() - t0
+        times = []
+        for _ in range(2):
+            t0 = time.perf_counter(); e = unet(x2, t, c2); times.append(time.perf_counter() - t0)
+        t_unet = float(np.mean(times))
+        t0 = time.perf_counter(); clip(torch.from_numpy(np.stack([IDS_UNCOND, IDS_COND]))); t_clip = time.perf_counter() - t0
+        t0 = time.perf_counter(); vae(torch.randn(1, 4, 64, 64) * 0.18215); t_vae = time.perf_counter() - t0
+    e_u, e_c = e.chunk(2)
+    e_ref = e_u + 7.5 * (e_c - e_u)
+    eg = e_gpu[:1].float().cpu()
+    rel = float((eg - e_ref).norm() / e_ref.norm())
+    t_img = 21 * t_unet + t_vae + t_clip
+    return {
+        'cpu_baseline': {'value': round(1.0 / t_img, 6), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+                         'unet_step_ms': round(1e3 * t_unet, 1),
+                         'sample': f'PyTorch-CPU fp32 oracle, same weights/inputs: 2 timed UNet evals (batch 2, 4x64x64; mean {t_unet:.2f}s, '
+                                   f'first {warm:.2f}s), 1 VAE decode 64x64->512x512 ({t_vae:.2f}s), 1 CLIP encode ({t_clip:.2f}s); '
+                                   f'image time = 21*t_unet + t_vae + t_clip = {t_img:.1f}s'},
+        'parity': {'guided_eps_rel_l2_gpu_f16_vs_cpu_f32': round(rel, 6), 'tolerance': 1e-2},
+    }
+
+
+if __name__ == '__main__':
+    main()

@@ -74,6 +74,12 @@ SDOD_API int sdod_graph_finalize(void* graph);
 SDOD_API int sdod_graph_io(void* graph, int is_output, int index, void** device_ptr, size_t* bytes);
 /* run once on `stream`.  use_hip_graph != 0: the launch list is captured on first use and replayed */
 SDOD_API int sdod_graph_execute(void* graph, void* stream, int use_hip_graph);
+/* launch list introspection + per-launch timing (HIP events on `stream`, eager, averaged over iters runs after one
+ * warm-up): label = kernel family/variant ("gemm_t2", "gemm_t3_splitk", "attn_d40", "group_norm", ...), flops/bytes =
+ * algorithmic work of that launch.  bench.py derives its roofline block from these. */
+SDOD_API int sdod_graph_num_ops(void* graph);
+SDOD_API int sdod_graph_op_info(void* graph, int index, const char** label, double* flops, double* bytes);
+SDOD_API int sdod_graph_profile(void* graph, void* stream, int iters, float* ms_out, int n);
 SDOD_API int sdod_graph_stats(void* graph, size_t* weight_bytes, size_t* arena_bytes, int* num_launches, double* flops);
 
 #ifdef __cplusplus

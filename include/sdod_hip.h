@@ -72,6 +72,8 @@ typedef struct sdod_gemm_desc {
 SDOD_API int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream);
 /* picks split_k / tile as the auto heuristic would; returns required workspace bytes */
 SDOD_API size_t sdod_gemm_workspace_bytes(const sdod_gemm_desc* d);
+/* which tile configuration (1: 128x128, 2: 128x64, 3: 64x64, 4: 256x16, 5: 64x128) and split-K factor the call would use */
+SDOD_API int sdod_gemm_plan(const sdod_gemm_desc* d, int* tile, int* splits);
 
 /* GroupNorm over NHWC [N][HW][C] (optionally the channel concat of x (c0) and x2 (c1)), G groups,
  * y = (x-mean)*rstd*w+b, optional SiLU.  dtype applies to x and y; weight/bias fp32 or NULL.

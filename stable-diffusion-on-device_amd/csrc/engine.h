@@ -109,7 +109,13 @@ private:
     void* io_alloc(std::vector<IoSlot>& v, size_t bytes);
 
     // ---- launch list
-    std::vector<std::function<void(hipStream_t)>> ops_;
+    struct Op {
+        std::function<void(hipStream_t)> fn;
+        std::string label;   // kernel family + variant, e.g. "gemm_t2", "gemm_t3_splitk", "attn_d40", "group_norm"
+        double flops = 0;    // algorithmic FLOPs of this launch (2*M*N*K, 4*B*H*Lq*Lk*D)
+        double bytes = 0;    // algorithmic HBM bytes of this launch (operands read once + result written once)
+    };
+    std::vector<Op> ops_;
     double flops_ = 0;
     hipGraphExec_t graph_exec_ = nullptr;
     hipGraph_t hip_graph_ = nullptr;
@@ -153,7 +159,15 @@ private:
     Act vae_attn_block(const std::string& pfx, const Act& x);
     int emb_total_ = 0; // sum of ResBlock output channels (set by the DECLARE pass)
     const char* group_base(const std::string& group) const;
-    void emit(std::function<void(hipStream_t)> fn) { if (mode_ == REAL) ops_.push_back(std::move(fn)); }
+    void emit(std::function<void(hipStream_t)> fn, const char* label = "elementwise", double flops = 0, double bytes = 0) {
+        if (mode_ == REAL) ops_.push_back(Op{std::move(fn), label, flops, bytes});
+    }
+
+public:
+    int num_ops() const { return (int)ops_.size(); }
+    const Op& op(int i) const { return ops_.at(i); }
+    // eager run with a HIP event pair around every launch; ms[i] = duration of op i (averaged over `iters` runs)
+    void profile(hipStream_t st, int iters, float* ms, int n);
 };
 
 } // namespace sdod

@@ -328,10 +328,18 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
     if (mode_ == DECLARE) return;
     ws_need_ = std::max(ws_need_, sdod_gemm_workspace_bytes(&d));
     if (mode_ != REAL) return;
-    flops_ += 2.0 * d.M * d.N * d.K;
+    const double fl = 2.0 * d.M * d.N * d.K;
+    flops_ += fl;
     d.workspace = ws_;
     d.workspace_bytes = ws_bytes_;
-    ops_.push_back([d](hipStream_t st) { check_rc(sdod_gemm_f16(&d, st)); });
+    int tile = 0, splits = 1;
+    (void)sdod_gemm_plan(&d, &tile, &splits);
+    std::string label = "gemm_t" + std::to_string(tile) + (splits > 1 ? "_splitk" : "");
+    // algorithmic bytes: A read once (conv: the image, not its im2col), W once, out written once (+ residual read)
+    double a_bytes = d.a_mode == SDOD_A_ROWS ? (double)d.M * d.K * 2
+                                             : (double)d.n_img * d.h_in * d.w_in * (d.c0 + d.c1) * 2;
+    double by = a_bytes + (double)d.N * d.K * 2 + (double)d.M * d.N * 2 * (d.residual ? 2 : 1);
+    ops_.push_back(Op{[d](hipStream_t st) { check_rc(sdod_gemm_f16(&d, st)); }, label, fl, by});
 }
 
 void Graph::linear_raw(const f16* x, int rows, int K, const f16* w, int ldw, int N, f16* out, const GemmOpt& o) {
@@ -390,9 +398,9 @@ Act Graph::group_norm(const Act& x, const Act* x2, int gw, int gb, float eps, bo
     const float* wp = W<float>(gw); const float* bp = W<float>(gb);
     const int n = x.n, hw = x.h * x.w, c0 = x.c, c1 = x2 ? x2->c : 0, si = silu ? 1 : 0;
     void* ws = gn_ws_;
-    ops_.push_back([=](hipStream_t st) {
+    ops_.push_back(Op{[=](hipStream_t st) {
         check_rc(sdod_group_norm_nhwc(xp, x2p, yp, wp, bp, n, hw, c0, c1, 32, eps, si, SDOD_F16, ws, st));
-    });
+    }, "group_norm", 0, 2.0 * n * hw * (c0 + c1) * 2});
     return y;
 }
 
@@ -402,19 +410,21 @@ Act Graph::layer_norm(const Act& x, int lw, int lb, float eps) {
     const void* xp = x.p; void* yp = y.p;
     const float* wp = W<float>(lw); const float* bp = W<float>(lb);
     const int m = x.rows(), c = x.c;
-    ops_.push_back([=](hipStream_t st) { check_rc(sdod_layer_norm_f16(xp, yp, wp, bp, m, c, eps, st)); });
+    ops_.push_back(Op{[=](hipStream_t st) { check_rc(sdod_layer_norm_f16(xp, yp, wp, bp, m, c, eps, st)); }, "layer_norm", 0,
+                      2.0 * m * c * 2});
     return y;
 }
 
 void Graph::attention(const f16* q, const f16* k, const f16* v, f16* out, int B, int heads, int lq, int lk, int d, int ldq,
                       int ldk, int ldv, int ldo, bool causal) {
     if (mode_ != REAL) return;
-    flops_ += 4.0 * B * heads * (double)lq * lk * d;
+    const double fl = 4.0 * B * heads * (double)lq * lk * d;
+    flops_ += fl;
     const float scale = 1.0f / sqrtf((float)d);
     const int ca = causal ? 1 : 0;
-    ops_.push_back([=](hipStream_t st) {
+    ops_.push_back(Op{[=](hipStream_t st) {
         check_rc(sdod_attention_f16(q, k, v, out, B, heads, lq, lk, d, ldq, ldk, ldv, ldo, scale, ca, st));
-    });
+    }, "attn_d" + std::to_string(d), fl, 2.0 * B * heads * d * (2.0 * lq + 2.0 * lk)});
 }
 
 // ------------------------------------------------------------------------------------------ finalize / run
@@ -459,7 +469,7 @@ void Graph::execute(hipStream_t st, bool use_hip_graph) {
     SDOD_REQUIRE(finalized_, "graph not finalized");
     if (!use_hip_graph || eager_runs_ == 0) {
         // the first run is always eager: it sets kernel attributes (dynamic LDS sizes), which must not happen in capture
-        for (auto& op : ops_) op(st);
+        for (auto& op : ops_) op.fn(st);
         ++eager_runs_;
         return;
     }
@@ -470,7 +480,7 @@ void Graph::execute(hipStream_t st, bool use_hip_graph) {
         SDOD_HIP_CHECK(hipStreamSynchronize(st));
         SDOD_HIP_CHECK(hipStreamBeginCapture(capture_stream_, hipStreamCaptureModeThreadLocal));
         try {
-            for (auto& op : ops_) op(capture_stream_);
+            for (auto& op : ops_) op.fn(capture_stream_);
         } catch (...) {
             hipGraph_t g = nullptr;
             (void)hipStreamEndCapture(capture_stream_, &g);
@@ -481,6 +491,31 @@ void Graph::execute(hipStream_t st, bool use_hip_graph) {
         SDOD_HIP_CHECK(hipGraphInstantiate(&graph_exec_, hip_graph_, nullptr, nullptr, 0));
     }
     SDOD_HIP_CHECK(hipGraphLaunch(graph_exec_, st));
+}
+
+void Graph::profile(hipStream_t st, int iters, float* ms, int n) {
+    SDOD_REQUIRE(finalized_, "graph not finalized");
+    SDOD_REQUIRE(ms != nullptr && n == (int)ops_.size() && iters > 0, "profile buffer must hold one float per op");
+    std::vector<hipEvent_t> ev(ops_.size() + 1);
+    for (auto& e : ev) SDOD_HIP_CHECK(hipEventCreate(&e));
+    std::vector<double> acc(ops_.size(), 0.0);
+    for (int it = 0; it < iters + 1; ++it) { // first pass is a warm-up
+        SDOD_HIP_CHECK(hipEventRecord(ev[0], st));
+        for (size_t i = 0; i < ops_.size(); ++i) {
+            ops_[i].fn(st);
+            SDOD_HIP_CHECK(hipEventRecord(ev[i + 1], st));
+        }
+        SDOD_HIP_CHECK(hipStreamSynchronize(st));
+        if (it == 0) continue;
+        for (size_t i = 0; i < ops_.size(); ++i) {
+            float t = 0.f;
+            SDOD_HIP_CHECK(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+            acc[i] += t;
+        }
+    }
+    for (size_t i = 0; i < ops_.size(); ++i) ms[i] = (float)(acc[i] / iters);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    ++eager_runs_;
 }
 
 void Graph::stats(size_t* wbytes, size_t* abytes, int* launches, double* flops) const {
@@ -581,6 +616,29 @@ extern "C" int sdod_graph_execute(void* graph, void* stream, int use_hip_graph) 
     SDOD_TRY
     SDOD_REQUIRE(graph != nullptr, "null graph");
     static_cast<Graph*>(graph)->execute((hipStream_t)stream, use_hip_graph != 0);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_graph_num_ops(void* graph) { return graph ? static_cast<Graph*>(graph)->num_ops() : 0; }
+
+extern "C" int sdod_graph_op_info(void* graph, int index, const char** label, double* flops, double* bytes) {
+    SDOD_TRY
+    SDOD_REQUIRE(graph != nullptr, "null graph");
+    auto* g = static_cast<Graph*>(graph);
+    SDOD_REQUIRE(index >= 0 && index < g->num_ops(), "op index out of range");
+    const auto& op = g->op(index);
+    if (label) *label = op.label.c_str();
+    if (flops) *flops = op.flops;
+    if (bytes) *bytes = op.bytes;
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_graph_profile(void* graph, void* stream, int iters, float* ms_out, int n) {
+    SDOD_TRY
+    SDOD_REQUIRE(graph != nullptr, "null graph");
+    static_cast<Graph*>(graph)->profile((hipStream_t)stream, iters, ms_out, n);
     return 0;
     SDOD_CATCH
 }

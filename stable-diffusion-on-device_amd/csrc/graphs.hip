@@ -134,7 +134,7 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     { GemmOpt o; o.bias = f1b; linear(n3.p, rows, C, f1w, 8 * C, ff, o); }
     release(n3);
     f16* gg = alloc((size_t)rows * 4 * C);
-    emit([=](hipStream_t st) { check_rc2(sdod_geglu_f16(ff, gg, rows, 4 * C, st)); });
+    emit([=](hipStream_t st) { check_rc2(sdod_geglu_f16(ff, gg, rows, 4 * C, st)); }, "geglu", 0, 3.0 * rows * 4 * C * 2);
     release(ff);
     Act t3 = act(B, 1, L, C);
     { GemmOpt o; o.bias = f2b; o.residual = t2.p; linear(gg, rows, 4 * C, f2w, C, t3.p, o); }
@@ -329,7 +329,7 @@ Act Graph::vae_attn_block(const std::string& pfx, const Act& x) {
         f16* sc = alloc((size_t)L * L);  // scores, softmaxed in place
         { GemmOpt o; o.alpha = 1.0f / sqrtf((float)C); o.lda = 2 * C;
           linear_raw(qk + (size_t)b * L * 2 * C, L, C, qk + (size_t)b * L * 2 * C + C, 2 * C, L, sc, o); }
-        emit([=](hipStream_t st) { check_rc2(sdod_softmax_rows_f16(sc, sc, L, L, st)); });
+        emit([=](hipStream_t st) { check_rc2(sdod_softmax_rows_f16(sc, sc, L, L, st)); }, "softmax_rows", 0, 2.0 * L * L * 2);
         linear_raw(sc, L, L, vt, L, C, att + (size_t)b * L * C, GemmOpt{});
         release(sc); release(vt);
     }
@@ -437,7 +437,8 @@ void Graph::build_clip() {
     const int fw = P("text_model.final_layer_norm.weight", {D}, PK_VEC), fb = P("text_model.final_layer_norm.bias", {D}, PK_VEC);
     if (mode_ == REAL) {
         const f16* xp = x.p; const float* wp = W<float>(fw); const float* bp = W<float>(fb);
-        ops_.push_back([=](hipStream_t st) { check_rc2(sdod_layer_norm_f16(xp, out, wp, bp, rows, D, 1e-5f, st)); });
+        ops_.push_back(Op{[=](hipStream_t st) { check_rc2(sdod_layer_norm_f16(xp, out, wp, bp, rows, D, 1e-5f, st)); }, "layer_norm", 0,
+                          2.0 * rows * D * 2});
     }
     release(x);
 }

@@ -21,7 +21,7 @@ class ModelConfig(ctypes.Structure):
 ENGINE_SYMBOLS = [
     'sdod_model_config_sd14', 'sdod_graph_create', 'sdod_graph_destroy', 'sdod_graph_num_params', 'sdod_graph_param_info',
     'sdod_graph_set_param', 'sdod_graph_load_file', 'sdod_graph_finalize', 'sdod_graph_io', 'sdod_graph_execute',
-    'sdod_graph_stats',
+    'sdod_graph_stats', 'sdod_graph_num_ops', 'sdod_graph_op_info', 'sdod_graph_profile',
 ]
 
 
@@ -42,6 +42,9 @@ def _engine():
         lib.sdod_graph_execute.argtypes = [P, P, I]
         lib.sdod_graph_stats.argtypes = [P, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(I),
                                          ctypes.POINTER(ctypes.c_double)]
+        lib.sdod_graph_num_ops.argtypes = [P]
+        lib.sdod_graph_op_info.argtypes = [P, I, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        lib.sdod_graph_profile.argtypes = [P, P, I, P, I]
         lib._sdod_engine_typed = True
     return lib
 
@@ -133,6 +136,22 @@ class Graph:
     def execute(self, use_hip_graph=False):
         check(self._lib.sdod_graph_execute(self._h, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream),
                                            1 if use_hip_graph else 0))
+
+    def op_table(self):
+        """[(label, flops, bytes)] for every launch of the graph"""
+        out = []
+        lab = ctypes.c_char_p(); fl = ctypes.c_double(); by = ctypes.c_double()
+        for i in range(self._lib.sdod_graph_num_ops(self._h)):
+            check(self._lib.sdod_graph_op_info(self._h, i, ctypes.byref(lab), ctypes.byref(fl), ctypes.byref(by)))
+            out.append((lab.value.decode(), fl.value, by.value))
+        return out
+
+    def profile(self, iters=3):
+        """per-launch durations in ms (HIP events on the current stream, eager); same order as op_table()"""
+        n = self._lib.sdod_graph_num_ops(self._h)
+        ms = (ctypes.c_float * n)()
+        check(self._lib.sdod_graph_profile(self._h, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), iters, ms, n))
+        return list(ms)
 
     def stats(self):
         w = ctypes.c_size_t(); a = ctypes.c_size_t(); n = ctypes.c_int(); f = ctypes.c_double()

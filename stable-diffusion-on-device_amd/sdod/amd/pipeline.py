@@ -1,0 +1,160 @@
+"""txt2img on MI355X: Python host loop over the engine graphs (north_star: "Python host code on PyTorch-ROCm drives
+the PLMS/DPM sampler loop while the UNet denoising step ... and the VAE decoder run as hand-written CDNA4 HIP kernels").
+
+Mirrors the reference's Context (context.cpp:49-403) in structure: setup -> graphs + cached unconditional embedding +
+cached time embeddings; generate -> tokenise, text-encode, sampler loop over the batched (uncond, cond) UNet
+evaluation with CFG, decode, uint8.  Multi-GPU: one process per GPU, images sharded over ranks, the text conditioning
+computed on rank 0 and sent with ONE RCCL broadcast."""
+import numpy as np
+import torch
+
+from . import engine as E
+from . import ops
+from .host import DpmSolver
+from .samplers import PLMS_ORDERS, PlmsSchedule
+
+
+class Txt2Img:
+    def __init__(self, state_dicts=None, models_dir=None, images_per_gpu=1, latent_hw=64, device='cuda:0', use_hip_graph=True,
+                 tokenizer=None, with_text_encoder=True):
+        """state_dicts: {'unet': sd, 'temb': sd, 'text': sd, 'vae': sd} in ldm/HF naming (canonical layouts), or models_dir
+        with the .sdodw containers libsdod_setup uses."""
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.n = images_per_gpu
+        self.cfg = E.sd14_config(latent_hw, latent_hw)
+        self.use_hip_graph = use_hip_graph
+        self.tokenizer = tokenizer
+        self.unet = E.UNet(self.cfg, 2 * self.n, device)
+        self.vae = E.VaeDecoder(self.cfg, 1, device)
+        self.text = E.TextEncoder(self.cfg, 2, device) if with_text_encoder else None
+        self._temb_graphs = {}
+        self._sd = state_dicts
+        self._dir = models_dir
+        for g, key, stem in ((self.unet, 'unet', 'unet'), (self.vae, 'vae', 'vae_decoder'), (self.text, 'text', 'text_encoder')):
+            if g is None:
+                continue
+            self._load(g, key, stem)
+            g.finalize()
+        self._temb_cache = {}
+
+    def _load(self, g, key, stem):
+        if self._sd is not None:
+            g.load_state_dict(self._sd[key])
+        else:
+            g.load_file(f'{self._dir}/{stem}.sdodw')
+
+    # ------------------------------------------------------------------ conditioning
+    def encode_tokens(self, ids_uncond, ids_cond):
+        """ids: int arrays [77]; returns fp16 [2, 77, 768] = (uncond, cond), computed on this GPU"""
+        ids = torch.from_numpy(np.stack([np.asarray(ids_uncond), np.asarray(ids_cond)]).astype(np.int32))
+        self.text.ids.copy_(ids)
+        self.text.execute(self.use_hip_graph)
+        return self.text.out.clone()
+
+    def encode_prompt(self, prompt, negative=''):
+        return self.encode_tokens(self.tokenizer.encode(negative), self.tokenizer.encode(prompt))
+
+    def time_embeddings(self, times):
+        """[len(times), 1280] fp16 for model times `times` (cached per schedule, as context.cpp:257-278 does)"""
+        key = tuple(float(t) for t in times)
+        if key not in self._temb_cache:
+            g = self._temb_graphs.get(len(key))
+            if g is None:
+                g = E.Temb(self.cfg, len(key), self.device)
+                self._load(g, 'temb', 'temb')
+                g.finalize()
+                self._temb_graphs[len(key)] = g
+            g.t.copy_(torch.tensor(key, dtype=torch.float32))
+            g.execute()
+            self._temb_cache[key] = g.out.clone()
+        return self._temb_cache[key]
+
+    # ------------------------------------------------------------------ one guided eps evaluation
+    def _set_context(self, ctx2):
+        n = self.n
+        self.unet.ctx[:n].copy_(ctx2[0:1].expand(n, -1, -1))
+        self.unet.ctx[n:].copy_(ctx2[1:2].expand(n, -1, -1))
+
+    def _eps(self, x, temb_row, guidance, mode):
+        """x: fp32 [n,4,H,W]; returns guided eps fp32 [n,4,H,W].  Batch rows: [uncond x n ; cond x n] (ldm order)."""
+        n = self.n
+        self.unet.x[:n].copy_(x); self.unet.x[n:].copy_(x)
+        self.unet.temb.copy_(temb_row.unsqueeze(0).expand(2 * n, -1))
+        self.unet.execute(self.use_hip_graph)
+        return ops.cfg_combine(self.unet.eps, guidance, uncond_first=True, mode=mode)
+
+    # ------------------------------------------------------------------ samplers
+    def sample_plms(self, ctx2, x_T, steps=20, guidance=7.5, trace=None):
+        sch = PlmsSchedule(steps)
+        temb = self.time_embeddings(sch.timesteps.astype(np.float32))     # row k <-> timestep index k
+        self._set_context(ctx2)
+        x = x_T.to(self.device, torch.float32).clone()
+        old = []
+        for i, step in enumerate(sch.time_range):
+            index = sch.steps - i - 1
+            e_t = self._eps(x, temb[index], guidance, mode=1)
+            if len(old) == 0:
+                x_pred = x.clone()
+                ops.ddim_step(x_pred, e_t, **sch.coef(index))
+                nxt = max(index - 1, 0)
+                e_next = self._eps(x_pred, temb[nxt], guidance, mode=1)
+                e_prime = ops.lincomb4([e_t, e_next], [1.0, 1.0], 2.0)
+            else:
+                k = min(len(old), 3)
+                coefs, div = PLMS_ORDERS[k]
+                e_prime = ops.lincomb4([e_t] + old[::-1][:k], coefs, div)
+            ops.ddim_step(x, e_prime, **sch.coef(index))
+            old.append(e_t)
+            old = old[-3:]
+            if trace is not None:
+                trace.append((int(step), index))
+        return x
+
+    def sample_dpm(self, ctx2, x_T, steps=20, guidance=7.5):
+        """the reference driver's sampler: DPM-Solver++(2M), CFG as g*e_c + (1-g)*e_u (context.cpp:342-382)"""
+        solver = DpmSolver()
+        model_ts = solver.prepare(steps)
+        temb = self.time_embeddings(model_ts[:steps])
+        self._set_context(ctx2)
+        x = x_T.to(self.device, torch.float32).clone()
+        y_prev = torch.zeros_like(x)
+        for s in range(steps):
+            e = self._eps(x, temb[s], guidance, mode=0)
+            ops.dpm_update(x, e, y_prev, **solver.coef(s))
+        return x
+
+    # ------------------------------------------------------------------ decode
+    def decode(self, latents, mode=1):
+        """latents fp32 [n,4,H,W] -> uint8 [n, 8H, 8W, 3] (mode 1 = ldm's 255*clamp((x+1)/2,0,1); mode 0 = reference driver)"""
+        outs = []
+        for i in range(latents.shape[0]):
+            self.vae.z.copy_(latents[i:i + 1])
+            self.vae.execute(self.use_hip_graph)
+            outs.append(ops.image_to_u8(self.vae.img, 0.5, 0.5, mode))
+        return torch.cat(outs, 0)
+
+    def generate(self, ctx2, x_T, steps=20, guidance=7.5, sampler='plms'):
+        z = self.sample_plms(ctx2, x_T, steps, guidance) if sampler == 'plms' else self.sample_dpm(ctx2, x_T, steps, guidance)
+        return self.decode(z, mode=1 if sampler == 'plms' else 0)
+
+
+def broadcast_conditioning(ctx2, src=0):
+    """the one collective of the path: CLIP output [2,77,768] fp16 (236,544 B) from rank `src` to every rank over RCCL"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(ctx2, src=src)
+    return ctx2
+
+
+def shard_images(total, rank, world):
+    """block distribution of image indices over ranks"""
+    per = (total + world - 1) // world
+    lo = min(total, rank * per)
+    return list(range(lo, min(total, lo + per)))
+
+
+def initial_latent(seed, image_index, shape=(4, 64, 64)):
+    """x_T for image `image_index`: CPU generator seeded with (seed, index) so any sharding yields the same images"""
+    g = torch.Generator().manual_seed(int(seed) * 1000003 + int(image_index))
+    return torch.randn((1,) + tuple(shape), generator=g)

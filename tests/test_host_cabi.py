@@ -1,0 +1,120 @@
+"""CPU tests (no GPU, no compute kernels): the C-ABI library loads, exports every symbol include/*.h declares, and its
+host-side pieces (C++ tokenizer, DPM solver tables, libsdod handle/error conventions) match the reference-generated
+golden vectors bit for bit."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import __graft_entry__ as ge
+    so = os.path.join(ge.PKG, 'lib', 'libsdod.so')
+    if not os.path.exists(so):
+        ge.build()
+    from sdod.amd import _lib
+    return _lib.load('libsdod.so')
+
+
+def test_every_declared_symbol_is_exported(lib):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    declared = set()
+    for h in ('sdod_hip.h', 'sdod_engine.h', 'sdod_host.h', 'libsdod.h'):
+        text = open(os.path.join(root, 'include', h)).read()
+        declared |= set(re.findall(r'(?:SDOD_API|LIBSDOD_API)\s+[\w\s\*]+?\b((?:sdod|libsdod)_\w+)\s*\(', text))
+    assert len(declared) >= 55, sorted(declared)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    from sdod.amd import _lib, engine, host
+    bound = set(_lib.HIP_SYMBOLS + engine.ENGINE_SYMBOLS + host.HOST_SYMBOLS + host.LIBSDOD_SYMBOLS)
+    assert declared - bound <= {'sdod_gemm_plan'}, declared - bound     # the Python side binds what the headers declare
+
+
+def test_cpp_dpm_solver_bit_exact_vs_reference_golden(lib, golden_dir):
+    from sdod.amd.host import DpmSolver
+    for steps in (20, 50):
+        g = json.load(open(os.path.join(golden_dir, f'dpm_steps{steps}.json')))
+        s = DpmSolver(1000, 0.00085, 0.0120)
+        mts = s.prepare(steps)
+        assert np.array_equal(mts.view(np.uint32), np.array(g['model_ts_bits'], np.uint32))
+        for name in ('ts', 'log_alphas', 'lambdas', 'sigmas', 'alphas', 'phis', 'i2rs', 'all_t', 'all_log_alpha'):
+            assert np.array_equal(s.table(name).view(np.uint32), np.array(g[name + '_bits'], np.uint32)), name
+        x = np.array(g['x0_bits'], np.uint32).view(np.float32).copy()
+        y_prev = np.zeros_like(x)
+        for i, rec in enumerate(g['trajectory']):
+            e = np.array(rec['eps_bits'], np.uint32).view(np.float32).copy()
+            s.update_host(i, x, e, y_prev)
+            assert np.array_equal(x.view(np.uint32), np.array(rec['x_bits'], np.uint32)), f'step {i}'
+        assert s.coef(0)['order'] == 1 and s.coef(1)['order'] == 2 and s.coef(steps - 1)['order'] == 2   # quirk Q8 kept
+
+
+def test_cpp_tokenizer_matches_reference_golden_and_oracle(lib, golden_dir):
+    from oracle.tokenizer_oracle import TokenizerOracle
+    from sdod.amd.host import Tokenizer
+    g = json.load(open(os.path.join(golden_dir, 'tokenizer_synthetic.json')))
+    vocab = os.path.join(golden_dir, g['vocab'])
+    tok = Tokenizer(vocab)
+    orc = TokenizerOracle(vocab, canonical_ws=True)
+    assert (tok.start_token, tok.end_token) == (orc.start_token, orc.end_token) == (554, 555)
+    for c in g['cases']:                       # ids produced by the reference's own tokenizer.cpp
+        assert tok.encode(c['text']).tolist() == c['ids'], c['text']
+    # beyond the reference's domain: Q3 inputs, non-blank whitespace, non-ASCII -- canonical semantics (oracle)
+    for text in ['aabc', 'tthe', 'a\nb\r\nc', 'line one\n\nline two', 'café CafÉ', 'über straße', 'x' * 400,
+                 'the ' * 90, "it's they'll we've", '']:
+        assert tok.encode(text).tolist() == orc.tokenize(text), repr(text)
+    assert tok.encode('A photograph of an astronaut riding a horse').tolist() == tok.encode('a  photograph of an astronaut riding a horse ').tolist()
+    with pytest.raises(Exception):
+        tok.encode(b'\xff\xfe'.decode('latin-1').encode('latin-1').decode('latin-1') and '\udcff')   # invalid UTF-8
+
+
+def test_tokenizer_missing_file_is_an_invalid_argument(lib):
+    from sdod.amd._lib import SdodError
+    from sdod.amd.host import Tokenizer
+    with pytest.raises(SdodError) as ei:
+        Tokenizer('/nonexistent/ctokenizer.txt')
+    assert ei.value.code == 2
+
+
+def test_libsdod_handle_and_error_conventions_without_gpu(lib):
+    """argument validation happens before any device work, so these paths run on a CPU-only box
+    (reference semantics: libsdod.cpp:48-63, :66-72, :187-209)"""
+    from sdod.amd import host
+    L = host._host()
+    assert L.libsdod_get_error_description(0) == b'No error'
+    assert L.libsdod_get_error_description(2) == b'Invalid argument'
+    assert L.libsdod_get_error_description(6) is None and L.libsdod_get_error_description(-1) is None
+    assert L.libsdod_setup(None, b'.', 4, 64, 8, 20, 1, 1) == 2                      # context == NULL
+    ctx = ctypes.c_void_p(1234)
+    assert L.libsdod_setup(ctypes.byref(ctx), b'.', 4, 64, 8, 20, 1, 1) == 2         # *context != NULL
+    ctx = ctypes.c_void_p()
+    assert L.libsdod_setup(ctypes.byref(ctx), b'.', 4, 64, 8, 20, 9, 1) == 2         # invalid log level
+    assert ctx.value is None
+    info = L.libsdod_get_last_error_extra_info(2, None)
+    assert info is not None and b'Invalid log_level' in info and b'capi.cpp' in info
+    for fn in (L.libsdod_release, L.libsdod_ref_context):
+        assert fn(None) == 1                                                          # INVALID_CONTEXT
+    assert L.libsdod_set_steps(None, 20) == 1 and L.libsdod_set_log_level(None, 1) == 1
+    assert b'context is nullptr' in L.libsdod_get_last_error_extra_info(1, None)
+    fake = (ctypes.c_uint * 8)(0xdeadbeef, 1, 1, 0, 0, 0, 0, 0)
+    assert L.libsdod_release(ctypes.cast(fake, ctypes.c_void_p)) == 1                 # magic mismatch
+    assert b'magic' in L.libsdod_get_last_error_extra_info(1, None)
+    assert L.libsdod_get_last_error_extra_info(99, None) is None
+
+
+def test_weight_container_roundtrip(tmp_path):
+    import torch
+    from sdod.amd import weights as Wt
+    sd = Wt.synthetic_state_dict([('a.weight', (8, 4, 3, 3)), ('a.bias', (8,)), ('n.weight', (8,)), ('tok.embedding.weight', (10, 4))], seed=3)
+    assert abs(float(sd['n.weight'].mean()) - 1.0) < 0.2 and float(sd['tok.embedding.weight'].abs().max()) < 0.2
+    again = Wt.synthetic_state_dict([('a.weight', (8, 4, 3, 3)), ('a.bias', (8,)), ('n.weight', (8,)), ('tok.embedding.weight', (10, 4))], seed=3)
+    assert all(torch.equal(sd[k], again[k]) for k in sd)
+    sd['h.weight'] = torch.randn(4, 4).half()
+    p = tmp_path / 'w.sdodw'
+    Wt.save(str(p), sd)
+    back = Wt.load(str(p))
+    assert list(back) == list(sd)
+    assert all(torch.equal(sd[k], back[k]) and sd[k].dtype == back[k].dtype for k in sd)
