@@ -35,6 +35,24 @@ IDS_COND = [49406, 320, 1125, 539, 550, 18376, 6765, 320, 4558] + [49407] * 68
 IDS_UNCOND = [49406] + [49407] * 76
 
 
+T0 = time.time()
+
+
+def log(msg):
+    """progress on stderr (the JSON line on stdout stays alone); also keeps long runs visibly alive"""
+    print(f'[bench {time.time() - T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """CPU share of this process: affinity mask, capped at 16 (the GPU box's per-GPU share; os.cpu_count() reports
+    every core of the host and would oversubscribe a cgroup-limited container)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -64,11 +82,14 @@ def main():
     from sdod.amd.pipeline import Txt2Img, broadcast_conditioning, initial_latent
 
     t_setup = time.time()
+    torch.set_num_threads(host_threads())
+    log(f'rank {rank}/{world}: generating synthetic weights ({host_threads()} host threads)')
     cfg = E.sd14_config(64, 64)
     n = args.images_per_gpu
     tables = {'unet': E.UNet(cfg, 2).param_table(), 'temb': E.Temb(cfg, 1).param_table(),
               'vae': E.VaeDecoder(cfg, 1).param_table(), 'text': E.TextEncoder(cfg, 1).param_table()}
     sds = {k: Wt.synthetic_state_dict(t, seed=1234 + i) for i, (k, t) in enumerate(tables.items())}
+    log('uploading weights / building graphs')
     pipe = Txt2Img(state_dicts=sds, images_per_gpu=n, latent_hw=64, device=f'cuda:{local_rank}',
                    use_hip_graph=not args.no_hip_graph)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
@@ -93,9 +114,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f'setup done in {setup_s:.1f}s; warm-up x{args.warmup}')
     for _ in range(args.warmup):
         img = one_image()
     barrier()
+    log(f'timing {args.steps} image(s) per GPU')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         img = one_image()
@@ -106,6 +129,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert img.shape == (n, 512, 512, 3) and img.dtype == torch.uint8
+    log(f'timed region: {elapsed:.3f}s for {args.steps} step(s)')
 
     # ---- per-UNet-step time (batched cond+uncond evaluation + CFG + sampler update), HIP-graph replay, same stream
     ctx2 = pipe.encode_tokens(ids_u, ids_c) if rank == 0 else torch.zeros(2, 77, 768, dtype=torch.float16, device=device)
@@ -127,6 +151,7 @@ def main():
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel family: per-launch HIP events over the UNet launch list (eager, same stream)
+        log(f'per-UNet-step {unet_step_ms:.3f} ms; profiling the launch list')
         table = pipe.unet.op_table()
         ms = pipe.unet.profile(iters=3)
         fam = {}
@@ -176,8 +201,9 @@ def main():
 def cpu_baseline_and_parity(pipe, sds, x_T, ctx2, e_gpu):
     """The oracle (CPU fp32 restatement) on the host cores, bounded sample; also the in-run parity number."""
     from oracle import sd_torch as S
-    threads = os.cpu_count() or 1
+    threads = host_threads()
     torch.set_num_threads(threads)
+    log(f'cpu baseline: building the oracle ({threads} threads)')
     with torch.device('meta'):
         unet, vae, clip = S.UNetModel(), S.AutoencoderKLDecode(), S.ClipTextModel()
     unet.load_state_dict({**sds['unet'], **sds['temb']}, assign=True)
@@ -190,12 +216,15 @@ def cpu_baseline_and_parity(pipe, sds, x_T, ctx2, e_gpu):
     with torch.no_grad():
         x2 = torch.cat([x, x]); c2 = torch.cat([c16[0:1], c16[1:2]])
         t0 = time.perf_counter(); e = unet(x2, t, c2); warm = time.perf_counter() - t0
+        log(f'cpu baseline: first UNet eval {warm:.1f}s')
         times = []
         for _ in range(2):
             t0 = time.perf_counter(); e = unet(x2, t, c2); times.append(time.perf_counter() - t0)
+            log(f'cpu baseline: UNet eval {times[-1]:.1f}s')
         t_unet = float(np.mean(times))
         t0 = time.perf_counter(); clip(torch.from_numpy(np.stack([IDS_UNCOND, IDS_COND]))); t_clip = time.perf_counter() - t0
         t0 = time.perf_counter(); vae(torch.randn(1, 4, 64, 64) * 0.18215); t_vae = time.perf_counter() - t0
+        log(f'cpu baseline: CLIP {t_clip:.1f}s, VAE decode {t_vae:.1f}s')
     e_u, e_c = e.chunk(2)
     e_ref = e_u + 7.5 * (e_c - e_u)
     eg = e_gpu[:1].float().cpu()

@@ -41,6 +41,9 @@ SDOD_API int sdod_dpm_update_host(void* solver, unsigned step, float* x, const f
 /* extension: reseed the latent generator of a libsdod context (the reference has Context::set_seed, context.cpp:285-289,
  * but no C entry point reaches it) */
 SDOD_API int sdod_context_set_seed(void* libsdod_context, unsigned seed);
+/* extension: inject x_T (fp32 NCHW, latent_channels*latent_spatial^2 values) for the NEXT libsdod_generate_image call
+ * instead of drawing it from the generator (context.cpp:333-334); parity runs need this (SURVEY 7.2 "RNG") */
+SDOD_API int sdod_context_set_initial_latent(void* libsdod_context, const float* x, size_t n);
 
 #ifdef __cplusplus
 }

@@ -293,6 +293,255 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2 main loop: LDS-DMA staging (global_load_lds_dwordx4: 1 KiB per wave-instruction straight into LDS, no VGPR
+// round trip, no ds_write) into a ring of STAGES slabs with the prefetch running STAGES-1 slabs ahead.  One raw
+// s_barrier per slab; loads stay in flight across it behind a counted s_waitcnt vmcnt(N) (the compiler-inserted
+// vmcnt(0) of __syncthreads() would drain them).  The LDS image is lane-linear per wave-instruction (8 rows x 8
+// chunks), so the XOR swizzle is applied to the per-lane SOURCE address and again on the fragment reads; rows that
+// do not exist (M/N tails, conv halo) read a zero line instead of being predicated, so every lane issues exactly the
+// same number of DMA ops and the vmcnt arithmetic stays exact.
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+template <int N>
+SDOD_DEVICE void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmP p, const f16* __restrict__ zeros) {
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_LD = BM / 32, B_LD = BN / 32; // DMA instructions per wave per slab (8 rows each)
+    constexpr int LOADS = A_LD + B_LD;
+    constexpr int STAGE = (BM + BN) * 64;         // halves per slab
+    constexpr int SC = BN + 8;
+    static_assert(WM * WN == 4 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
+    static_assert(LOADS * (STAGES - 1) < 64, "vmcnt is a 6-bit counter");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    f16* smem = reinterpret_cast<f16*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int lid = xcd_remap(blockIdx.x, nwg);
+    const int tile_m = lid / p.tiles_n;
+    const int tile_n = lid - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.z;
+
+    const int KT = p.K / BK;
+    int kt_begin = 0, kt_end = KT;
+    if (p.splits > 1) {
+        kt_begin = split * p.kt_per_split;
+        kt_end = min(KT, kt_begin + p.kt_per_split);
+    }
+    const int nkt = kt_end - kt_begin;
+
+    // lane covers row (lane>>3) of an 8-row group and PHYSICAL chunk (lane&7); it must fetch the logical chunk that
+    // the swizzle maps there: c = phys ^ (row & 7), and row & 7 == lane>>3 because groups start at multiples of 8
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ lrow;
+
+    int a_img[A_LD], a_oy[A_LD], a_ox[A_LD];
+    bool a_ok[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int m = m0 + (i * 4 + wave) * 8 + lrow;
+        a_ok[i] = m < p.M;
+        if (p.mode == SDOD_A_CONV3X3) {
+            const int hw = p.h_out * p.w_out;
+            const int mm = a_ok[i] ? m : 0;
+            const int img = mm / hw;
+            const int rem = mm - img * hw;
+            const int oy = rem / p.w_out;
+            a_img[i] = img;
+            a_oy[i] = oy * p.stride;
+            a_ox[i] = (rem - oy * p.w_out) * p.stride;
+        } else {
+            a_img[i] = m;
+            a_oy[i] = 0;
+            a_ox[i] = 0;
+        }
+    }
+    const f16* b_row[B_LD];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+        const int n = n0 + (i * 4 + wave) * 8 + lrow;
+        b_row[i] = n < p.N ? p.w + (size_t)n * p.ldw + lchunk * 8 : nullptr;
+    }
+    const int cin = p.c0 + p.c1;
+    const int hup = p.h_in << p.ups, wup = p.w_in << p.ups;
+
+    auto issue_tile = [&](int kt, int stage) {
+        const int k0 = kt * BK;
+        f16* sA = smem + stage * STAGE;
+        f16* sB = sA + BM * 64;
+        if (p.mode == SDOD_A_CONV3X3) {
+            const int tap = k0 / cin;
+            const int cc = k0 - tap * cin;
+            const int r = tap / p.ksize, s = tap - r * p.ksize;
+            const int pad = p.ksize >> 1;
+            const f16* src = p.a0;
+            int csrc = p.c0, ccs = cc;
+            if (cc >= p.c0) {
+                src = p.a1;
+                csrc = p.c1;
+                ccs = cc - p.c0;
+            }
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                int yy = a_oy[i] + r - pad, xx = a_ox[i] + s - pad;
+                const bool ok = a_ok[i] && yy >= 0 && yy < hup && xx >= 0 && xx < wup;
+                yy >>= p.ups;
+                xx >>= p.ups;
+                const size_t off = ((size_t)(a_img[i] * p.h_in + yy) * p.w_in + xx) * csrc + ccs + lchunk * 8;
+                const f16* g = ok ? src + off : zeros;
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sA + (i * 4 + wave) * 8 * 64), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                const f16* g = a_ok[i] ? p.a0 + (size_t)a_img[i] * p.lda + k0 + lchunk * 8 : zeros;
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sA + (i * 4 + wave) * 8 * 64), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const f16* g = b_row[i] ? b_row[i] + k0 : zeros;
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * 4 + wave) * 8 * 64), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frag_row = lane & 15;
+    const int frag_chunk = lane >> 4;
+
+    // prologue: STAGES-1 slabs in flight (issue even past the end -- against the zero line -- so counts stay uniform)
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) {
+        if (s < nkt) issue_tile(kt_begin + s, s);
+    }
+
+    for (int it = 0; it < nkt; ++it) {
+        // slab `it` has landed once at most the younger in-flight slabs remain outstanding
+        const int younger = min(STAGES - 2, nkt - 1 - it);
+        if (younger >= STAGES - 2 && STAGES > 2) wait_vmcnt<LOADS * (STAGES - 2)>();
+        else if (younger == 1 && STAGES > 3) wait_vmcnt<LOADS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier(); // everyone's slab `it` is in LDS; everyone is done reading slab it-1
+        if (it + STAGES - 1 < nkt) issue_tile(kt_begin + it + STAGES - 1, (it + STAGES - 1) % STAGES);
+
+        const f16* sA = smem + (it % STAGES) * STAGE;
+        const f16* sB = sA + BM * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 xa[TM], wb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                xa[i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WTM + i * 16 + frag_row, ks * 4 + frag_chunk));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                wb[j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(wb[j], xa[i], acc[i][j]);
+        }
+    }
+    wait_vmcnt<0>();
+    __syncthreads(); // all fragment reads done before the epilogue tile overwrites the ring
+
+    const int e_m = lane & 15;
+    const int e_n = (lane >> 4) * 4;
+    if (p.splits > 1) {
+        float* slab = p.partial + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + e_m;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + e_n;
+                if (n + 3 < p.N) {
+                    *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + n) = acc[i][j];
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N) slab[(size_t)m * p.N + n + r] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
+
+    f16* sC = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = wm * WTM + i * 16 + e_m;
+        const int m = m0 + ml;
+        const f16* rbias = nullptr;
+        if (p.row_bias != nullptr && m < p.M) rbias = p.row_bias + (size_t)(m / p.rows_per_img) * p.ldrb;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn * WTN + j * 16 + e_n;
+            const int n = n0 + nl;
+            f16x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[i][j][r] * p.alpha;
+                if (p.bias != nullptr) {
+                    if (p.bias_on_m) {
+                        if (m < p.M) v += p.bias[m];
+                    } else if (n + r < p.N) {
+                        v += p.bias[n + r];
+                    }
+                }
+                if (rbias != nullptr && n + r < p.N) v += (float)rbias[n + r];
+                v = apply_act(v, p.act);
+                h[r] = (f16)v;
+            }
+            *reinterpret_cast<f16x4*>(sC + ml * SC + nl) = h;
+        }
+    }
+    __syncthreads();
+
+    constexpr int CPR = BN / 8;
+    const bool vec_ok = (p.N % 8 == 0) && (p.ldo % 8 == 0) && (p.residual == nullptr || p.ldr % 8 == 0);
+    for (int idx = tid; idx < BM * CPR; idx += 256) {
+        const int row = idx / CPR;
+        const int ch = idx - row * CPR;
+        const int m = m0 + row, n = n0 + ch * 8;
+        if (m >= p.M || n >= p.N) continue;
+        f16x8 v = *reinterpret_cast<const f16x8*>(sC + row * SC + ch * 8);
+        if (vec_ok) {
+            if (p.residual != nullptr) {
+                const f16x8 rr = ldg8(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)rr[e]);
+            }
+            stg8(p.out + (size_t)m * p.ldo + n, v);
+        } else {
+            for (int e = 0; e < 8; ++e) {
+                if (n + e < p.N) {
+                    float f = (float)v[e];
+                    if (p.residual != nullptr) f += (float)p.residual[(size_t)m * p.ldr + n + e];
+                    p.out[(size_t)m * p.ldo + n + e] = (f16)f;
+                }
+            }
+        }
+    }
+}
+
 // Reduce split-K slabs and apply the fused epilogue.  One thread per 4 consecutive columns.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
     const int n4 = (p.N + 3) / 4;
@@ -329,8 +578,36 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
 struct TileCfg {
     int bm, bn;
 };
-// id 1..5
-const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {256, 16}, {64, 128}};
+// id 1..5: register-staged kernel; 6..8: LDS-DMA ring kernel (v2)
+const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {256, 16}, {64, 128}, {128, 128}, {128, 64}, {64, 64}};
+constexpr int kNumTiles = 8;
+
+const f16* zero_line() {
+    static f16* z = nullptr;
+    if (!z) {
+        if (hipMalloc((void**)&z, 256) != hipSuccess) return nullptr;
+        (void)hipMemset(z, 0, 256);
+    }
+    return z;
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+hipError_t launch_glds(const GemmP& p, dim3 grid, hipStream_t st) {
+    constexpr size_t ring = (size_t)STAGES * (BM + BN) * 64 * sizeof(f16);
+    constexpr size_t ctile = (size_t)BM * (BN + 8) * sizeof(f16);
+    constexpr size_t smem = ring > ctile ? ring : ctile;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, STAGES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const f16* z = zero_line();
+    if (!z) return hipErrorOutOfMemory;
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(256), smem, st, p, z);
+    return hipGetLastError();
+}
 
 template <int BM, int BN, int WM, int WN>
 hipError_t launch_cfg(const GemmP& p, dim3 grid, hipStream_t st) {
@@ -357,7 +634,7 @@ Plan make_plan(const sdod_gemm_desc* d) {
     const int KT = d->K / BK;
     auto ntiles = [&](int t) { return ((d->M + kTiles[t].bm - 1) / kTiles[t].bm) * ((d->N + kTiles[t].bn - 1) / kTiles[t].bn); };
     int tile = d->tile;
-    if (tile <= 0 || tile > 5) {
+    if (tile <= 0 || tile > kNumTiles) {
         if (d->N <= 16) {
             tile = 4;
         } else {
@@ -470,7 +747,10 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     case 2: e = launch_cfg<128, 64, 2, 2>(p, grid, st); break;
     case 3: e = launch_cfg<64, 64, 2, 2>(p, grid, st); break;
     case 4: e = launch_cfg<256, 16, 4, 1>(p, grid, st); break;
-    default: e = launch_cfg<64, 128, 2, 2>(p, grid, st); break;
+    case 5: e = launch_cfg<64, 128, 2, 2>(p, grid, st); break;
+    case 6: e = launch_glds<128, 128, 2, 2, 3>(p, grid, st); break;
+    case 7: e = launch_glds<128, 64, 2, 2, 4>(p, grid, st); break;
+    default: e = launch_glds<64, 64, 2, 2, 4>(p, grid, st); break;
     }
     SDOD_HIP_CHECK(e);
     if (pl.splits > 1) {

@@ -288,4 +288,10 @@ int sdod_context_set_seed(void* libsdod_context, unsigned seed) {
     return LIBSDOD_NO_ERROR;
 }
 
+int sdod_context_set_initial_latent(void* libsdod_context, const float* x, size_t n) {
+    Handle* h;
+    if (int rc = retrieve(libsdod_context, &h, __func__)) return rc;
+    return guarded(h->ctx, __func__, [&]() { h->ctx->set_initial_latent(x, n); });
+}
+
 } // extern "C"

@@ -1,5 +1,6 @@
 #include "context.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -121,6 +122,12 @@ void Context::set_seed(unsigned seed) {
     rng_.seed(seed);
 }
 
+void Context::set_initial_latent(const float* x, size_t n) {
+    SDOD_REQUIRE(x != nullptr && n == x_host_.size(), "initial latent must have latent_channels*latent_spatial^2 floats");
+    std::copy(x, x + n, x_host_.begin());
+    injected_ = true;
+}
+
 void Context::generate(const std::string& prompt, float guidance, unsigned char* out) {
     SDOD_REQUIRE(unet_ && text_ && vae_ && temb_cache_ && steps_ > 0, "context is not initialised");
     SDOD_HIP_CHECK(hipSetDevice(device_));
@@ -140,7 +147,9 @@ void Context::generate(const std::string& prompt, float guidance, unsigned char*
     SDOD_HIP_CHECK(hipMemcpyAsync(static_cast<char*>(uc.ptr) + ctx_bytes, ctx_uncond_, ctx_bytes, hipMemcpyDeviceToDevice, stream_));
     logger_.info("Conditioning took " + std::to_string((long)t.ms()) + "ms");
 
-    for (auto& f : x_host_) f = normal_(rng_); // context.cpp:333-334
+    if (!injected_)
+        for (auto& f : x_host_) f = normal_(rng_); // context.cpp:333-334
+    injected_ = false;
     SDOD_HIP_CHECK(hipMemcpyAsync(x_dev_, x_host_.data(), lat * sizeof(float), hipMemcpyHostToDevice, stream_));
 
     for (unsigned step = 0; step < steps_; ++step) {

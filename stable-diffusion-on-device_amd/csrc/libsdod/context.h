@@ -41,6 +41,7 @@ public:
     void init(unsigned steps);                 // context.cpp:49-80 (load everything, then the schedule)
     void prepare_schedule(unsigned steps);     // context.cpp:245-282 (any steps >= 1; the reference accepts only 20)
     void set_seed(unsigned seed);              // context.cpp:285-289
+    void set_initial_latent(const float* x, size_t n); // parity runs inject x_T (RNG streams are not portable)
     size_t image_bytes() const { return (size_t)3 * latent_spatial_ * upscale_ * latent_spatial_ * upscale_; }
     void generate(const std::string& prompt, float guidance, unsigned char* out); // context.cpp:292-403
 
@@ -71,6 +72,7 @@ private:
     float* x_dev_ = nullptr;      // latent, fp32 NCHW
     uint8_t* img_u8_ = nullptr;
     std::vector<float> x_host_;
+    bool injected_ = false;
 
     void encode_prompt(const std::string& prompt, f16* dst);
     std::string weight_path(const char* stem) const { return models_dir_ + "/" + stem + ".sdodw"; }

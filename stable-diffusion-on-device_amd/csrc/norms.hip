@@ -134,16 +134,25 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnP p) {
     }
 }
 
+// one wave per (n, group): lanes stride over the chunk partials (independent loads in flight), then a shuffle reduce
 template <typename T>
-__global__ void gn_finalize_kernel(const GnP p) {
-    const int n = blockIdx.x;
-    for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
-        float a = 0.f, b = 0.f;
-        for (int ch = 0; ch < p.nchunks; ++ch) {
-            const float* src = p.partial + (((size_t)n * p.nchunks + ch) * p.G + g) * 2;
-            a += src[0];
-            b += src[1];
-        }
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnP p) {
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= p.G) return;
+    float a = 0.f, b = 0.f;
+    for (int ch = lane; ch < p.nchunks; ch += 64) {
+        const float* src = p.partial + (((size_t)n * p.nchunks + ch) * p.G + g) * 2;
+        a += src[0];
+        b += src[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+    }
+    if (lane == 0) {
         const float cnt = (float)p.HW * (float)p.Cg;
         const float shift = (float)*gn_src<T>(p, n, 0, g * p.Cg);
         const float md = a / cnt;
@@ -204,7 +213,7 @@ void gn_launch(GnP& p, hipStream_t st) {
     else
         hipLaunchKernelGGL((gn_stats_kernel<T, 2>), sgrid, sblock, smem_stats, st, p);
     SDOD_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(p.N), dim3(64), 0, st, p);
+    hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3((p.G + 3) / 4, p.N), dim3(256), 0, st, p);
     SDOD_HIP_CHECK(hipGetLastError());
     const size_t total = (size_t)p.HW * cp;
     int bx = (int)((total + 255) / 256);

@@ -8,7 +8,7 @@ from . import _lib
 
 HOST_SYMBOLS = [
     'sdod_tokenizer_create', 'sdod_tokenizer_destroy', 'sdod_tokenizer_encode', 'sdod_tokenizer_special', 'sdod_dpm_create',
-    'sdod_dpm_destroy', 'sdod_dpm_prepare', 'sdod_dpm_table', 'sdod_dpm_coef', 'sdod_dpm_update_host', 'sdod_context_set_seed',
+    'sdod_dpm_destroy', 'sdod_dpm_prepare', 'sdod_dpm_table', 'sdod_dpm_coef', 'sdod_dpm_update_host', 'sdod_context_set_seed', 'sdod_context_set_initial_latent',
 ]
 LIBSDOD_SYMBOLS = [
     'libsdod_setup', 'libsdod_set_steps', 'libsdod_set_log_level', 'libsdod_ref_context', 'libsdod_release',
@@ -32,6 +32,7 @@ def _host():
         lib.sdod_dpm_coef.argtypes = [P, U, PP(I), PP(F), PP(F), PP(F), PP(F), PP(F)]
         lib.sdod_dpm_update_host.argtypes = [P, U, P, P, P, U]
         lib.sdod_context_set_seed.argtypes = [P, U]
+        lib.sdod_context_set_initial_latent.argtypes = [P, P, ctypes.c_size_t]
         lib.libsdod_setup.argtypes = [PP(P), ctypes.c_char_p, U, U, U, U, U, I]
         lib.libsdod_set_steps.argtypes = [P, U]
         lib.libsdod_set_log_level.argtypes = [P, U]
@@ -132,6 +133,10 @@ class LibSdod:
 
     def set_seed(self, seed):
         return self.lib.sdod_context_set_seed(self.ctx, seed)
+
+    def set_initial_latent(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        return self.lib.sdod_context_set_initial_latent(self.ctx, x.ctypes.data, x.size)
 
     def set_steps(self, steps):
         return self.lib.libsdod_set_steps(self.ctx, steps)

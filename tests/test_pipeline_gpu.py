@@ -3,8 +3,8 @@ injected x_T, guidance 7.5.  Reduced latent (16x16) keeps the CPU side in tens o
 covered by properties (finite, deterministic, sharding-invariant) and by bench.py's in-run parity block.
 
 Stated tolerances (fp16 GPU vs fp32 CPU): final latent rel-L2 <= 2e-2; uint8 image within 2 LSB on
->= 99% of pixels... relaxed to >= 97% because with *synthetic* weights the decoder output is high-contrast noise, not
-a natural image (documented in DESIGN.md); scheduler index sequences exact."""
+>= 99% of pixels (measured: max diff 1 LSB, 100% within 2 LSB).
+Scheduler index sequences exact."""
 import numpy as np
 import pytest
 import torch
@@ -64,7 +64,7 @@ def test_plms_20_steps_matches_oracle(rig):
     diff = np.abs(img.astype(np.int32) - img_ref.astype(np.int32))
     frac = float((diff <= 2).mean())
     print('uint8 image: max diff', int(diff.max()), 'mean', float(diff.mean()), 'within 2 LSB', frac)
-    assert img.shape == (1, 128, 128, 3) and frac >= 0.97, frac
+    assert img.shape == (1, 128, 128, 3) and frac >= 0.99, frac
 
 
 def test_dpm_driver_loop_matches_oracle(rig, oracle_lib):
@@ -82,7 +82,7 @@ def test_dpm_driver_loop_matches_oracle(rig, oracle_lib):
     img_ref = PO.decode_u8(vae, z_ref, mode=0, oracle_lib=oracle_lib)
     frac = float((np.abs(img.astype(np.int32) - img_ref.astype(np.int32)) <= 2).mean())
     print('dpm uint8 within 2 LSB', frac)
-    assert frac >= 0.97, frac
+    assert frac >= 0.99, frac
 
 
 def test_pipeline_is_deterministic_and_sharding_invariant(rig):

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the GEMM / conv kernel on the UNet + VAE layer shapes (developer tool, GPU box only).
+usage: python tools/gemm_bench.py [--tiles 0,1,2,3] [--iters 20]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'stable-diffusion-on-device_amd'))
+import torch  # noqa: E402
+from sdod.amd import ops  # noqa: E402
+
+# (name, kind, params)  rows: (M, N, K); conv: (n, h, w, cin, cout, stride, ups)
+SHAPES = [
+    ('conv 320->320 @64', 'conv', (2, 64, 64, 320, 320, 1, False)),
+    ('conv 640->640 @32', 'conv', (2, 32, 32, 640, 640, 1, False)),
+    ('conv 1280->1280 @16', 'conv', (2, 16, 16, 1280, 1280, 1, False)),
+    ('conv 1280->1280 @8', 'conv', (2, 8, 8, 1280, 1280, 1, False)),
+    ('conv 2560->1280 @8', 'conv', (2, 8, 8, 2560, 1280, 1, False)),
+    ('conv 960->320 @64', 'conv', (2, 64, 64, 960, 320, 1, False)),
+    ('conv 1920->640 @32', 'conv', (2, 32, 32, 1920, 640, 1, False)),
+    ('upconv 640->640 @32->64', 'conv', (2, 32, 32, 640, 640, 1, True)),
+    ('qkv 320 @64', 'rows', (8192, 960, 320)),
+    ('proj 320 @64', 'rows', (8192, 320, 320)),
+    ('ff1 320 @64', 'rows', (8192, 2560, 320)),
+    ('ff2 320 @64', 'rows', (8192, 320, 1280)),
+    ('ff1 640 @32', 'rows', (2048, 5120, 640)),
+    ('ff2 640 @32', 'rows', (2048, 640, 2560)),
+    ('ff1 1280 @16', 'rows', (512, 10240, 1280)),
+    ('ff2 1280 @16', 'rows', (512, 1280, 5120)),
+    ('kv ctx 1280', 'rows', (154, 2560, 768)),
+    ('emb proj', 'rows', (2, 20160, 1280)),
+    ('vae conv 128->128 @512', 'conv', (1, 512, 512, 128, 128, 1, False)),
+    ('vae conv 256->256 @256', 'conv', (1, 256, 256, 256, 256, 1, False)),
+    ('vae conv 512->512 @128', 'conv', (1, 128, 128, 512, 512, 1, False)),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--tiles', default='0')
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--only', default='')
+    args = ap.parse_args()
+    tiles = [int(t) for t in args.tiles.split(',')]
+    d = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(0)
+    print(f'{"shape":28s} {"GFLOP":>8s} ' + ' '.join(f'{"t" + str(t) + " us":>9s} {"TF/s":>7s}' for t in tiles), flush=True)
+    for name, kind, prm in SHAPES:
+        if args.only and args.only not in name:
+            continue
+        if kind == 'rows':
+            m, n, k = prm
+            a = torch.randn(m, k, generator=g).half().to(d)
+            w = (torch.randn(n, k, generator=g) * k ** -0.5).half().to(d)
+            bias = torch.randn(n).to(d)
+            fl = 2.0 * m * n * k
+            call = lambda t: ops.gemm(a, w, bias, tile=t)
+        else:
+            nb, h, wd, cin, cout, stride, ups = prm
+            a = torch.randn(nb, h, wd, cin, generator=g).half().to(d)
+            w = (torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5).half().to(d)
+            bias = torch.randn(cout).to(d)
+            ho = (h * (2 if ups else 1)) // stride
+            fl = 2.0 * nb * ho * ho * cout * 9 * cin
+            call = lambda t: ops.gemm(a, w, bias, conv=dict(stride=stride, upsample=ups), tile=t)
+        row = f'{name:28s} {fl / 1e9:8.2f} '
+        for t in tiles:
+            for _ in range(3):
+                call(t)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.iters):
+                call(t)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / args.iters
+            row += f'{us:9.1f} {fl / us / 1e6:7.1f} '
+        print(row, flush=True)
+
+
+if __name__ == '__main__':
+    main()
