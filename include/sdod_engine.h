@@ -79,6 +79,7 @@ SDOD_API int sdod_graph_execute(void* graph, void* stream, int use_hip_graph);
  * algorithmic work of that launch.  bench.py derives its roofline block from these. */
 SDOD_API int sdod_graph_num_ops(void* graph);
 SDOD_API int sdod_graph_op_info(void* graph, int index, const char** label, double* flops, double* bytes);
+SDOD_API int sdod_graph_op_detail(void* graph, int index, const char** detail); /* shape string of launch `index` */
 SDOD_API int sdod_graph_profile(void* graph, void* stream, int iters, float* ms_out, int n);
 SDOD_API int sdod_graph_stats(void* graph, size_t* weight_bytes, size_t* arena_bytes, int* num_launches, double* flops);
 

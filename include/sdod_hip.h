@@ -74,6 +74,8 @@ SDOD_API int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream);
 SDOD_API size_t sdod_gemm_workspace_bytes(const sdod_gemm_desc* d);
 /* which tile configuration (1: 128x128, 2: 128x64, 3: 64x64, 4: 256x16, 5: 64x128) and split-K factor the call would use */
 SDOD_API int sdod_gemm_plan(const sdod_gemm_desc* d, int* tile, int* splits);
+/* developer aid: average duration in ms of `iters` back-to-back launches (HIP events on `stream`) */
+SDOD_API int sdod_gemm_time(const sdod_gemm_desc* d, void* stream, int iters, float* ms_avg);
 
 /* GroupNorm over NHWC [N][HW][C] (optionally the channel concat of x (c0) and x2 (c1)), G groups,
  * y = (x-mean)*rstd*w+b, optional SiLU.  dtype applies to x and y; weight/bias fp32 or NULL.

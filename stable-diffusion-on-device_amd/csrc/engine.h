@@ -114,6 +114,7 @@ private:
         std::string label;   // kernel family + variant, e.g. "gemm_t2", "gemm_t3_splitk", "attn_d40", "group_norm"
         double flops = 0;    // algorithmic FLOPs of this launch (2*M*N*K, 4*B*H*Lq*Lk*D)
         double bytes = 0;    // algorithmic HBM bytes of this launch (operands read once + result written once)
+        std::string detail;  // shape, for the per-layer profile table (tools/unet_profile.py)
     };
     std::vector<Op> ops_;
     double flops_ = 0;
@@ -160,7 +161,7 @@ private:
     int emb_total_ = 0; // sum of ResBlock output channels (set by the DECLARE pass)
     const char* group_base(const std::string& group) const;
     void emit(std::function<void(hipStream_t)> fn, const char* label = "elementwise", double flops = 0, double bytes = 0) {
-        if (mode_ == REAL) ops_.push_back(Op{std::move(fn), label, flops, bytes});
+        if (mode_ == REAL) ops_.push_back(Op{std::move(fn), label, flops, bytes, ""});
     }
 
 public:

@@ -7,6 +7,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -324,10 +325,63 @@ IoSlot Graph::io(bool output, int index) const {
 }
 
 // ------------------------------------------------------------------------------------------ emitters
+// ---- tile autotuning: "measure, don't guess".  Every distinct GEMM shape of a graph is timed once per process with
+// each candidate tile configuration of gemm.hip (a few back-to-back launches on the real operands, HIP events) and the
+// fastest is baked into the launch list.  Disable with SDOD_AUTOTUNE=0 (then gemm.hip's static heuristic decides).
+namespace {
+const int kCandidates[] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16};
+
+struct ShapeKey {
+    int v[12];
+    bool operator<(const ShapeKey& o) const { return std::lexicographical_compare(v, v + 12, o.v, o.v + 12); }
+};
+std::map<ShapeKey, int>& tune_cache() {
+    static std::map<ShapeKey, int> c;
+    return c;
+}
+bool autotune_enabled() {
+    const char* e = std::getenv("SDOD_AUTOTUNE");
+    return !(e && e[0] == '0');
+}
+ShapeKey key_of(const sdod_gemm_desc& d) {
+    return ShapeKey{{d.a_mode, d.M, d.N, d.K, d.c0, d.c1, d.stride, d.upsample, d.ksize, d.h_in, d.residual ? 1 : 0, d.lda}};
+}
+} // namespace
+
 void Graph::emit_gemm(sdod_gemm_desc d) {
     if (mode_ == DECLARE) return;
+    const bool tune = autotune_enabled() && d.N > 16;
+    if (tune) {
+        for (int t : kCandidates) {
+            sdod_gemm_desc c = d;
+            c.tile = t;
+            ws_need_ = std::max(ws_need_, sdod_gemm_workspace_bytes(&c));
+        }
+    }
     ws_need_ = std::max(ws_need_, sdod_gemm_workspace_bytes(&d));
     if (mode_ != REAL) return;
+    if (tune) {
+        d.workspace = ws_;
+        d.workspace_bytes = ws_bytes_;
+        const ShapeKey key = key_of(d);
+        auto it = tune_cache().find(key);
+        if (it == tune_cache().end()) {
+            int best = 0;
+            float best_ms = 1e30f;
+            for (int t : kCandidates) {
+                sdod_gemm_desc c = d;
+                c.tile = t;
+                float ms = 0.f;
+                if (sdod_gemm_time(&c, nullptr, 4, &ms) != 0) continue;
+                if (ms < best_ms) {
+                    best_ms = ms;
+                    best = t;
+                }
+            }
+            it = tune_cache().emplace(key, best).first;
+        }
+        d.tile = it->second;
+    }
     const double fl = 2.0 * d.M * d.N * d.K;
     flops_ += fl;
     d.workspace = ws_;
@@ -339,7 +393,10 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
     double a_bytes = d.a_mode == SDOD_A_ROWS ? (double)d.M * d.K * 2
                                              : (double)d.n_img * d.h_in * d.w_in * (d.c0 + d.c1) * 2;
     double by = a_bytes + (double)d.N * d.K * 2 + (double)d.M * d.N * 2 * (d.residual ? 2 : 1);
-    ops_.push_back(Op{[d](hipStream_t st) { check_rc(sdod_gemm_f16(&d, st)); }, label, fl, by});
+    std::string detail = (d.a_mode == SDOD_A_ROWS ? std::string("rows") : "conv" + std::to_string(d.ksize) + (d.upsample ? "u" : "") +
+                                                                          (d.stride == 2 ? "s2" : "") + (d.c1 ? "+cat" : "")) +
+                         " M" + std::to_string(d.M) + " N" + std::to_string(d.N) + " K" + std::to_string(d.K) + " x" + std::to_string(splits);
+    ops_.push_back(Op{[d](hipStream_t st) { check_rc(sdod_gemm_f16(&d, st)); }, label, fl, by, detail});
 }
 
 void Graph::linear_raw(const f16* x, int rows, int K, const f16* w, int ldw, int N, f16* out, const GemmOpt& o) {
@@ -400,7 +457,7 @@ Act Graph::group_norm(const Act& x, const Act* x2, int gw, int gb, float eps, bo
     void* ws = gn_ws_;
     ops_.push_back(Op{[=](hipStream_t st) {
         check_rc(sdod_group_norm_nhwc(xp, x2p, yp, wp, bp, n, hw, c0, c1, 32, eps, si, SDOD_F16, ws, st));
-    }, "group_norm", 0, 2.0 * n * hw * (c0 + c1) * 2});
+    }, "group_norm", 0, 2.0 * n * hw * (c0 + c1) * 2, "n" + std::to_string(n) + " hw" + std::to_string(hw) + " c" + std::to_string(c0 + c1)});
     return y;
 }
 
@@ -411,7 +468,7 @@ Act Graph::layer_norm(const Act& x, int lw, int lb, float eps) {
     const float* wp = W<float>(lw); const float* bp = W<float>(lb);
     const int m = x.rows(), c = x.c;
     ops_.push_back(Op{[=](hipStream_t st) { check_rc(sdod_layer_norm_f16(xp, yp, wp, bp, m, c, eps, st)); }, "layer_norm", 0,
-                      2.0 * m * c * 2});
+                      2.0 * m * c * 2, "m" + std::to_string(m) + " c" + std::to_string(c)});
     return y;
 }
 
@@ -424,7 +481,8 @@ void Graph::attention(const f16* q, const f16* k, const f16* v, f16* out, int B,
     const int ca = causal ? 1 : 0;
     ops_.push_back(Op{[=](hipStream_t st) {
         check_rc(sdod_attention_f16(q, k, v, out, B, heads, lq, lk, d, ldq, ldk, ldv, ldo, scale, ca, st));
-    }, "attn_d" + std::to_string(d), fl, 2.0 * B * heads * d * (2.0 * lq + 2.0 * lk)});
+    }, "attn_d" + std::to_string(d), fl, 2.0 * B * heads * d * (2.0 * lq + 2.0 * lk),
+                      "B" + std::to_string(B) + " h" + std::to_string(heads) + " lq" + std::to_string(lq) + " lk" + std::to_string(lk)});
 }
 
 // ------------------------------------------------------------------------------------------ finalize / run
@@ -621,6 +679,16 @@ extern "C" int sdod_graph_execute(void* graph, void* stream, int use_hip_graph) 
 }
 
 extern "C" int sdod_graph_num_ops(void* graph) { return graph ? static_cast<Graph*>(graph)->num_ops() : 0; }
+
+extern "C" int sdod_graph_op_detail(void* graph, int index, const char** detail) {
+    SDOD_TRY
+    SDOD_REQUIRE(graph != nullptr && detail != nullptr, "null argument");
+    auto* g = static_cast<Graph*>(graph);
+    SDOD_REQUIRE(index >= 0 && index < g->num_ops(), "op index out of range");
+    *detail = g->op(index).detail.c_str();
+    return 0;
+    SDOD_CATCH
+}
 
 extern "C" int sdod_graph_op_info(void* graph, int index, const char** label, double* flops, double* bytes) {
     SDOD_TRY

@@ -40,6 +40,7 @@ struct GemmP {
     int lda, ldw, ldo, ldr;
     int mode;
     int h_in, w_in, h_out, w_out, c0, c1, stride, ups, ksize;
+    int sa0, sa1; // pixel strides (elements) of the two A sources: c0/c1 for NHWC images, lda for plain rows
     int rows_per_img, ldrb;
     int act;
     float alpha;
@@ -310,14 +311,17 @@ SDOD_DEVICE void wait_vmcnt() {
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmP p, const f16* __restrict__ zeros) {
+__global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, const f16* __restrict__ zeros) {
+    constexpr int NW = WM * WN;                   // waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD, so one
+                                                  // wave's DMA issue / LDS reads overlap its partner's MFMAs)
+    constexpr int NT = 64 * NW;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int A_LD = BM / 32, B_LD = BN / 32; // DMA instructions per wave per slab (8 rows each)
+    constexpr int A_LD = BM / (8 * NW), B_LD = BN / (8 * NW); // DMA instructions per wave per slab (8 rows each)
     constexpr int LOADS = A_LD + B_LD;
     constexpr int STAGE = (BM + BN) * 64;         // halves per slab
     constexpr int SC = BN + 8;
-    static_assert(WM * WN == 4 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
+    static_assert((NW == 4 || NW == 8) && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && TM >= 1 && TN >= 1, "tile shape");
     static_assert(LOADS * (STAGES - 1) < 64, "vmcnt is a 6-bit counter");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -348,73 +352,79 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmP p, const f16
     const int lrow = lane >> 3;
     const int lchunk = (lane & 7) ^ lrow;
 
-    int a_img[A_LD], a_oy[A_LD], a_ox[A_LD];
-    bool a_ok[A_LD];
+    // Per-row gather state, computed once.  Rows mode is the same code with n_img = M, 1x1 "image", pixel stride lda.
+    //   a_ro0/1 : element offset of tap (0,0) of this row in source 0 / 1 (+ this lane's chunk), 32-bit
+    //   a_mask  : bit t set <=> tap t of this row exists (row < M and the pixel is inside the image)
+    // Every slab then costs one scalar delta + a handful of VALU per DMA instruction (no divisions, no branches).
+    int a_ro0[A_LD], a_ro1[A_LD], a_py[A_LD], a_px[A_LD], a_im[A_LD];
+    unsigned a_mask[A_LD];
+    const int pad = p.ksize >> 1;
+    const int hup = p.h_in << p.ups, wup = p.w_in << p.ups;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-        const int m = m0 + (i * 4 + wave) * 8 + lrow;
-        a_ok[i] = m < p.M;
-        if (p.mode == SDOD_A_CONV3X3) {
-            const int hw = p.h_out * p.w_out;
-            const int mm = a_ok[i] ? m : 0;
-            const int img = mm / hw;
-            const int rem = mm - img * hw;
-            const int oy = rem / p.w_out;
-            a_img[i] = img;
-            a_oy[i] = oy * p.stride;
-            a_ox[i] = (rem - oy * p.w_out) * p.stride;
-        } else {
-            a_img[i] = m;
-            a_oy[i] = 0;
-            a_ox[i] = 0;
+        const int m = m0 + (i * NW + wave) * 8 + lrow;
+        const bool row_ok = m < p.M;
+        const int hw = p.h_out * p.w_out;
+        const int mm = row_ok ? m : 0;
+        const int img = mm / hw;
+        const int rem = mm - img * hw;
+        const int oy = rem / p.w_out;
+        const int py = oy * p.stride - pad, px = (rem - oy * p.w_out) * p.stride - pad;
+        a_py[i] = py; a_px[i] = px; a_im[i] = img * p.h_in;
+        const int pix = (img * p.h_in + py) * p.w_in + px;
+        a_ro0[i] = pix * p.sa0 + lchunk * 8;
+        a_ro1[i] = pix * p.sa1 + lchunk * 8;
+        unsigned mask = 0;
+        for (int t = 0; t < p.ksize * p.ksize; ++t) {
+            const int r = t / p.ksize, sx = t - r * p.ksize;
+            const bool ok = row_ok & ((unsigned)(py + r) < (unsigned)hup) & ((unsigned)(px + sx) < (unsigned)wup);
+            mask |= (ok ? 1u : 0u) << t;
         }
+        a_mask[i] = mask;
     }
     const f16* b_row[B_LD];
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
-        const int n = n0 + (i * 4 + wave) * 8 + lrow;
-        b_row[i] = n < p.N ? p.w + (size_t)n * p.ldw + lchunk * 8 : nullptr;
+        const int n = n0 + (i * NW + wave) * 8 + lrow;
+        b_row[i] = n < p.N ? p.w + (size_t)n * p.ldw + lchunk * 8 : zeros;
     }
+    const int b_step = 0; (void)b_step;
     const int cin = p.c0 + p.c1;
-    const int hup = p.h_in << p.ups, wup = p.w_in << p.ups;
 
     auto issue_tile = [&](int kt, int stage) {
         const int k0 = kt * BK;
         f16* sA = smem + stage * STAGE;
         f16* sB = sA + BM * 64;
-        if (p.mode == SDOD_A_CONV3X3) {
-            const int tap = k0 / cin;
-            const int cc = k0 - tap * cin;
-            const int r = tap / p.ksize, s = tap - r * p.ksize;
-            const int pad = p.ksize >> 1;
-            const f16* src = p.a0;
-            int csrc = p.c0, ccs = cc;
-            if (cc >= p.c0) {
-                src = p.a1;
-                csrc = p.c1;
-                ccs = cc - p.c0;
-            }
+        const int tap = k0 / cin;
+        const int cc = k0 - tap * cin;
+        const int r = tap / p.ksize, sx = tap - r * p.ksize;
+        const bool second = cc >= p.c0;
+        const f16* src = second ? p.a1 : p.a0;
+        const int sa = second ? p.sa1 : p.sa0;
+        const int ccs = second ? cc - p.c0 : cc;
+        if (!p.ups) {
+            const int sdelta = (r * p.w_in + sx) * sa + ccs; // wave-uniform
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) {
-                int yy = a_oy[i] + r - pad, xx = a_ox[i] + s - pad;
-                const bool ok = a_ok[i] && yy >= 0 && yy < hup && xx >= 0 && xx < wup;
-                yy >>= p.ups;
-                xx >>= p.ups;
-                const size_t off = ((size_t)(a_img[i] * p.h_in + yy) * p.w_in + xx) * csrc + ccs + lchunk * 8;
-                const f16* g = ok ? src + off : zeros;
-                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sA + (i * 4 + wave) * 8 * 64), 16, 0, 0);
+                const int ro = (second ? a_ro1[i] : a_ro0[i]) + sdelta;
+                const bool ok = (a_mask[i] >> tap) & 1u;
+                const f16* g = ok ? src + ro : zeros;
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sA + (i * NW + wave) * 8 * 64), 16, 0, 0);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) {
-                const f16* g = a_ok[i] ? p.a0 + (size_t)a_img[i] * p.lda + k0 + lchunk * 8 : zeros;
-                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sA + (i * 4 + wave) * 8 * 64), 16, 0, 0);
+                const int yy = (a_py[i] + r) >> 1, xx = (a_px[i] + sx) >> 1;
+                const int ro = ((a_im[i] + yy) * p.w_in + xx) * sa + ccs + lchunk * 8;
+                const bool ok = (a_mask[i] >> tap) & 1u;
+                const f16* g = ok ? src + ro : zeros;
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sA + (i * NW + wave) * 8 * 64), 16, 0, 0);
             }
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
-            const f16* g = b_row[i] ? b_row[i] + k0 : zeros;
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * 4 + wave) * 8 * 64), 16, 0, 0);
+            const f16* g = b_row[i] + (b_row[i] == zeros ? 0 : k0);
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * NW + wave) * 8 * 64), 16, 0, 0);
         }
     };
 
@@ -517,7 +527,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmP p, const f16
 
     constexpr int CPR = BN / 8;
     const bool vec_ok = (p.N % 8 == 0) && (p.ldo % 8 == 0) && (p.residual == nullptr || p.ldr % 8 == 0);
-    for (int idx = tid; idx < BM * CPR; idx += 256) {
+    for (int idx = tid; idx < BM * CPR; idx += NT) {
         const int row = idx / CPR;
         const int ch = idx - row * CPR;
         const int m = m0 + row, n = n0 + ch * 8;
@@ -579,8 +589,11 @@ struct TileCfg {
     int bm, bn;
 };
 // id 1..5: register-staged kernel; 6..8: LDS-DMA ring kernel (v2)
-const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {256, 16}, {64, 128}, {128, 128}, {128, 64}, {64, 64}};
-constexpr int kNumTiles = 8;
+// 9..12: v2 with 8 waves (2 per SIMD)
+const TileCfg kTiles[] = {{0, 0},     {128, 128}, {128, 64}, {64, 64},   {256, 16}, {64, 128}, {128, 128},
+                          {128, 64},  {64, 64},   {128, 128}, {256, 128}, {128, 64}, {256, 64},
+                          {128, 128}, {128, 128}, {256, 128}, {256, 256}};
+constexpr int kNumTiles = 16;
 
 const f16* zero_line() {
     static f16* z = nullptr;
@@ -605,7 +618,7 @@ hipError_t launch_glds(const GemmP& p, dim3 grid, hipStream_t st) {
     }
     const f16* z = zero_line();
     if (!z) return hipErrorOutOfMemory;
-    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(256), smem, st, p, z);
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(64 * WM * WN), smem, st, p, z);
     return hipGetLastError();
 }
 
@@ -719,6 +732,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         SDOD_REQUIRE(!(d->upsample && d->stride != 1), "upsample implies stride 1");
         p.h_in = d->h_in; p.w_in = d->w_in; p.c0 = d->c0; p.c1 = d->c1;
         p.stride = d->stride; p.ups = d->upsample ? 1 : 0;
+        p.sa0 = d->c0; p.sa1 = d->c1;
         const int hup = d->h_in << p.ups, wup = d->w_in << p.ups;
         p.h_out = (hup + 2 * (ks / 2) - ks) / d->stride + 1;
         p.w_out = (wup + 2 * (ks / 2) - ks) / d->stride + 1;
@@ -727,6 +741,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         SDOD_REQUIRE(d->a_mode == SDOD_A_ROWS, "unknown a_mode");
         SDOD_REQUIRE(d->lda >= d->K && d->lda % 8 == 0, "lda must be >= K and a multiple of 8");
         p.c0 = d->K; p.c1 = 0; p.h_in = p.w_in = p.h_out = p.w_out = 1; p.stride = 1; p.ksize = 1;
+        p.sa0 = d->lda; p.sa1 = 0;
     }
     const Plan pl = make_plan(d);
     p.splits = pl.splits;
@@ -750,7 +765,15 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     case 5: e = launch_cfg<64, 128, 2, 2>(p, grid, st); break;
     case 6: e = launch_glds<128, 128, 2, 2, 3>(p, grid, st); break;
     case 7: e = launch_glds<128, 64, 2, 2, 4>(p, grid, st); break;
-    default: e = launch_glds<64, 64, 2, 2, 4>(p, grid, st); break;
+    case 8: e = launch_glds<64, 64, 2, 2, 4>(p, grid, st); break;
+    case 9: e = launch_glds<128, 128, 2, 4, 3>(p, grid, st); break;
+    case 10: e = launch_glds<256, 128, 4, 2, 2>(p, grid, st); break;
+    case 11: e = launch_glds<128, 64, 4, 2, 4>(p, grid, st); break;
+    case 12: e = launch_glds<256, 64, 4, 2, 3>(p, grid, st); break;
+    case 13: e = launch_glds<128, 128, 2, 4, 4>(p, grid, st); break;
+    case 14: e = launch_glds<128, 128, 2, 4, 2>(p, grid, st); break;
+    case 15: e = launch_glds<256, 128, 4, 2, 3>(p, grid, st); break;
+    default: e = launch_glds<256, 256, 2, 4, 2>(p, grid, st); break;
     }
     SDOD_HIP_CHECK(e);
     if (pl.splits > 1) {
@@ -760,6 +783,35 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
         SDOD_HIP_CHECK(hipGetLastError());
     }
+    return 0;
+    SDOD_CATCH
+}
+
+// developer aid: average duration (ms) of `iters` back-to-back launches, timed with HIP events on `stream`
+// (the Python launch path costs ~15 us per call, which hides kernels shorter than that)
+extern "C" int sdod_gemm_time(const sdod_gemm_desc* d, void* stream, int iters, float* ms_avg) {
+    SDOD_TRY
+    SDOD_REQUIRE(d && ms_avg && iters > 0, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < 3; ++i) {
+        const int rc = sdod_gemm_f16(d, stream);
+        if (rc) return rc;
+    }
+    hipEvent_t e0, e1;
+    SDOD_HIP_CHECK(hipEventCreate(&e0));
+    SDOD_HIP_CHECK(hipEventCreate(&e1));
+    SDOD_HIP_CHECK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) {
+        const int rc = sdod_gemm_f16(d, stream);
+        if (rc) return rc;
+    }
+    SDOD_HIP_CHECK(hipEventRecord(e1, st));
+    SDOD_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    SDOD_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_avg = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return 0;
     SDOD_CATCH
 }

@@ -438,7 +438,7 @@ void Graph::build_clip() {
     if (mode_ == REAL) {
         const f16* xp = x.p; const float* wp = W<float>(fw); const float* bp = W<float>(fb);
         ops_.push_back(Op{[=](hipStream_t st) { check_rc2(sdod_layer_norm_f16(xp, out, wp, bp, rows, D, 1e-5f, st)); }, "layer_norm", 0,
-                          2.0 * rows * D * 2});
+                          2.0 * rows * D * 2, ""});
     }
     release(x);
 }

@@ -10,8 +10,8 @@
 // kernel would read 20..160-byte fragments.  Instead the statistics pass reads whole pixel rows (fully
 // coalesced 16-byte lanes, many workgroups), every thread owning a fixed 8-channel chunk and keeping
 // per-channel shifted sums in registers; per-group partials go through LDS to a small fp32 scratch.
-// A tiny finalize kernel produces mean/rstd per (n,g); the apply pass is a vectorised elementwise
-// kernel whose per-channel scale/shift live in LDS, with SiLU fused (every ResBlock site) and the
+// The apply pass first reduces those partials to mean/rstd per (n,g) (fixed order, one wave per group -- cheaper than
+// a third launch), then runs as a vectorised elementwise kernel whose per-channel scale/shift live in LDS, with SiLU fused (every ResBlock site) and the
 // channel concat of the UNet skip connections folded into the reads.  Sums are shifted by a per-group
 // pilot value (first element of the group) so E[x^2]-E[x]^2 cancellation stays harmless in fp32.
 // Algorithmic bytes: N*HW*C*sizeof(T) read twice + written once (the second read is L2/MALL resident).
@@ -134,45 +134,46 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnP p) {
     }
 }
 
-// one wave per (n, group): lanes stride over the chunk partials (independent loads in flight), then a shuffle reduce
-template <typename T>
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnP p) {
-    const int n = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= p.G) return;
-    float a = 0.f, b = 0.f;
-    for (int ch = lane; ch < p.nchunks; ch += 64) {
-        const float* src = p.partial + (((size_t)n * p.nchunks + ch) * p.G + g) * 2;
-        a += src[0];
-        b += src[1];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        a += __shfl_xor(a, o);
-        b += __shfl_xor(b, o);
-    }
-    if (lane == 0) {
-        const float cnt = (float)p.HW * (float)p.Cg;
-        const float shift = (float)*gn_src<T>(p, n, 0, g * p.Cg);
-        const float md = a / cnt;
-        float var = b / cnt - md * md;
-        var = var < 0.f ? 0.f : var;
-        p.stats[((size_t)n * p.G + g) * 2 + 0] = shift + md;
-        p.stats[((size_t)n * p.G + g) * 2 + 1] = 1.0f / sqrtf(var + p.eps);
-    }
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sc = reinterpret_cast<float*>(smem_raw); // [C] scale
     float* sh = sc + p.C;                            // [C] shift
+    float* gm = sh + p.C;                            // [G] mean
+    float* gr = gm + p.G;                            // [G] rstd
     const int n = blockIdx.y;
+    // finalize the statistics here (every workgroup redoes this small, fixed-order reduction; it costs less than the
+    // extra launch a separate finalize kernel would): one wave per group, lanes stride over the chunk partials
+    {
+        const int lane = threadIdx.x & 63;
+        for (int g = threadIdx.x >> 6; g < p.G; g += blockDim.x >> 6) {
+            float a = 0.f, b = 0.f;
+            for (int ch = lane; ch < p.nchunks; ch += 64) {
+                const float* src = p.partial + (((size_t)n * p.nchunks + ch) * p.G + g) * 2;
+                a += src[0];
+                b += src[1];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                a += __shfl_xor(a, o);
+                b += __shfl_xor(b, o);
+            }
+            if (lane == 0) {
+                const float cnt = (float)p.HW * (float)p.Cg;
+                const float shift = (float)*gn_src<T>(p, n, 0, g * p.Cg);
+                const float md = a / cnt;
+                float var = b / cnt - md * md;
+                var = var < 0.f ? 0.f : var;
+                gm[g] = shift + md;
+                gr[g] = 1.0f / sqrtf(var + p.eps);
+            }
+        }
+    }
+    __syncthreads();
     for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
         const int g = c / p.Cg;
-        const float mean = p.stats[((size_t)n * p.G + g) * 2 + 0];
-        const float rstd = p.stats[((size_t)n * p.G + g) * 2 + 1];
+        const float mean = gm[g];
+        const float rstd = gr[g];
         const float w = p.w ? p.w[c] : 1.0f;
         const float b = p.b ? p.b[c] : 0.0f;
         sc[c] = rstd * w;
@@ -213,17 +214,15 @@ void gn_launch(GnP& p, hipStream_t st) {
     else
         hipLaunchKernelGGL((gn_stats_kernel<T, 2>), sgrid, sblock, smem_stats, st, p);
     SDOD_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3((p.G + 3) / 4, p.N), dim3(256), 0, st, p);
-    SDOD_HIP_CHECK(hipGetLastError());
     const size_t total = (size_t)p.HW * cp;
     int bx = (int)((total + 255) / 256);
-    const int cap = 2048 / (p.N > 0 ? p.N : 1) + 1;
+    const int cap = 1024 / (p.N > 0 ? p.N : 1) + 1;
     if (bx > cap) bx = cap;
-    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(bx, p.N), dim3(256), (size_t)p.C * 2 * sizeof(float), st, p);
+    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(bx, p.N), dim3(256), ((size_t)p.C * 2 + (size_t)p.G * 2) * sizeof(float), st, p);
     SDOD_HIP_CHECK(hipGetLastError());
 }
 
-constexpr int GN_MAX_CHUNKS = 128;
+constexpr int GN_MAX_CHUNKS = 64;
 
 // ---------------------------------------------------------------- LayerNorm: one wave per row
 __global__ __launch_bounds__(256) void layer_norm_kernel(const f16* x, f16* y, const float* w, const float* b, int M,

@@ -21,7 +21,7 @@ class ModelConfig(ctypes.Structure):
 ENGINE_SYMBOLS = [
     'sdod_model_config_sd14', 'sdod_graph_create', 'sdod_graph_destroy', 'sdod_graph_num_params', 'sdod_graph_param_info',
     'sdod_graph_set_param', 'sdod_graph_load_file', 'sdod_graph_finalize', 'sdod_graph_io', 'sdod_graph_execute',
-    'sdod_graph_stats', 'sdod_graph_num_ops', 'sdod_graph_op_info', 'sdod_graph_profile',
+    'sdod_graph_stats', 'sdod_graph_num_ops', 'sdod_graph_op_info', 'sdod_graph_op_detail', 'sdod_graph_profile',
 ]
 
 
@@ -45,6 +45,7 @@ def _engine():
         lib.sdod_graph_num_ops.argtypes = [P]
         lib.sdod_graph_op_info.argtypes = [P, I, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         lib.sdod_graph_profile.argtypes = [P, P, I, P, I]
+        lib.sdod_graph_op_detail.argtypes = [P, I, ctypes.POINTER(ctypes.c_char_p)]
         lib._sdod_engine_typed = True
     return lib
 
@@ -144,6 +145,14 @@ class Graph:
         for i in range(self._lib.sdod_graph_num_ops(self._h)):
             check(self._lib.sdod_graph_op_info(self._h, i, ctypes.byref(lab), ctypes.byref(fl), ctypes.byref(by)))
             out.append((lab.value.decode(), fl.value, by.value))
+        return out
+
+    def op_details(self):
+        out = []
+        det = ctypes.c_char_p()
+        for i in range(self._lib.sdod_graph_num_ops(self._h)):
+            check(self._lib.sdod_graph_op_detail(self._h, i, ctypes.byref(det)))
+            out.append(det.value.decode())
         return out
 
     def profile(self, iters=3):

@@ -45,7 +45,7 @@ def workspace(nbytes, device, tag='default'):
 
 
 def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=None, alpha=1.0, out=None,
-         conv=None, a2=None, bias_on_m=False, split_k=0, tile=0):
+         conv=None, a2=None, bias_on_m=False, split_k=0, tile=0, time_iters=0):
     """out = act(alpha * A @ W^T + bias + row_bias) + residual.
 
     a: fp16 [M, K] (rows mode) or NHWC [N, H, W, C0] with conv=dict(stride=1|2, upsample=bool) (3x3 pad 1);
@@ -103,6 +103,10 @@ def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=N
     if need:
         ws = workspace(need, a.device, 'gemm')
         d.workspace = _p(ws); d.workspace_bytes = ws.numel() * 4
+    if time_iters:
+        ms = ctypes.c_float()
+        check(lib.sdod_gemm_time(ctypes.byref(d), _stream(), time_iters, ctypes.byref(ms)))
+        return ms.value
     check(lib.sdod_gemm_f16(ctypes.byref(d), _stream()))
     return out
 

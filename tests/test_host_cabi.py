@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert not missing, missing
     from sdod.amd import _lib, engine, host
     bound = set(_lib.HIP_SYMBOLS + engine.ENGINE_SYMBOLS + host.HOST_SYMBOLS + host.LIBSDOD_SYMBOLS)
-    assert declared - bound <= {'sdod_gemm_plan'}, declared - bound     # the Python side binds what the headers declare
+    assert not (declared - bound), declared - bound     # the Python side binds what the headers declare
 
 
 def test_cpp_dpm_solver_bit_exact_vs_reference_golden(lib, golden_dir):

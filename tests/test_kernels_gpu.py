@@ -48,6 +48,9 @@ def test_library_and_device():
 # ------------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('m,n,k,tile', [
     (256, 128, 64, 1), (256, 128, 128, 2), (200, 72, 192, 3), (512, 16, 128, 4), (100, 136, 64, 5),
+    (256, 128, 64, 6), (300, 200, 128, 6), (8192, 320, 320, 6), (256, 128, 192, 7), (333, 72, 640, 7), (200, 72, 64, 8),
+    (1000, 320, 1280, 8), (128, 1280, 1280, 6), (128, 1280, 1280, 8),
+    (300, 200, 128, 9), (8192, 320, 320, 9), (300, 200, 192, 10), (1000, 320, 1280, 10), (333, 72, 640, 11), (700, 136, 256, 12),
     (8192, 320, 320, 0), (333, 320, 640, 0), (128, 1280, 1280, 0), (77 * 2, 768, 768, 0), (4096, 4, 64, 0),
     (1000, 3, 1152, 0),
 ])
@@ -63,8 +66,9 @@ def test_gemm_rows(m, n, k, tile):
     check(out, ref, name=f'gemm {m}x{n}x{k} tile{tile}')
 
 
+@pytest.mark.parametrize('tile', [0, 6, 8, 9, 10])
 @pytest.mark.parametrize('split', [2, 5, 16])
-def test_gemm_split_k(split):
+def test_gemm_split_k(split, tile):
     from sdod.amd import ops
     m, n, k = 128, 320, 2880
     a = rnd((m, k), 5); w = rnd((n, k), 6, k ** -0.5)
@@ -72,8 +76,8 @@ def test_gemm_split_k(split):
     rb = torch.randn(2, n, generator=torch.Generator().manual_seed(8)).half()
     ref = a.float() @ w.float().t() + bias + rb.float().repeat_interleave(64, 0)
     d = dev()
-    out = ops.gemm(a.to(d), w.to(d), bias.to(d), row_bias=rb.to(d), rows_per_img=64, split_k=split)
-    check(out, ref, name=f'splitk {split}')
+    out = ops.gemm(a.to(d), w.to(d), bias.to(d), row_bias=rb.to(d), rows_per_img=64, split_k=split, tile=tile)
+    check(out, ref, name=f'splitk {split} tile{tile}')
 
 
 def test_gemm_bias_on_m_and_gelu():
@@ -99,19 +103,20 @@ def conv_ref(x_nhwc, w_krsc, bias, stride=1, upsample=False):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
+@pytest.mark.parametrize('tile', [0, 6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize('n,h,w,cin,cout,stride,ups', [
     (2, 16, 16, 64, 128, 1, False), (1, 9, 7, 128, 64, 1, False), (2, 16, 16, 64, 64, 2, False),
     (1, 8, 8, 128, 128, 1, True), (2, 64, 64, 320, 320, 1, False), (2, 8, 8, 1280, 1280, 1, False),
     (1, 7, 7, 64, 64, 2, False),
 ])
-def test_conv3x3(n, h, w, cin, cout, stride, ups):
+def test_conv3x3(n, h, w, cin, cout, stride, ups, tile):
     from sdod.amd import ops
     x = rnd((n, h, w, cin), 20); wt = rnd((cout, 9 * cin), 21, (9 * cin) ** -0.5)
     bias = torch.randn(cout, generator=torch.Generator().manual_seed(22))
     ref = conv_ref(x, wt, bias, stride, ups)
     d = dev()
-    out = ops.gemm(x.to(d), wt.to(d), bias.to(d), conv=dict(stride=stride, upsample=ups))
-    check(out, ref, name=f'conv {n}x{h}x{w} {cin}->{cout} s{stride} u{ups}')
+    out = ops.gemm(x.to(d), wt.to(d), bias.to(d), conv=dict(stride=stride, upsample=ups), tile=tile)
+    check(out, ref, name=f'conv {n}x{h}x{w} {cin}->{cout} s{stride} u{ups} tile{tile}')
 
 
 def test_conv3x3_concat_rowbias_residual():
@@ -125,9 +130,10 @@ def test_conv3x3_concat_rowbias_residual():
     ref = conv_ref(torch.cat([x0, x1], -1), wt, bias) + rb.float()[:, None, None, :]
     ref = ref.half().float() + res.float()
     d = dev()
-    out = ops.gemm(x0.to(d), wt.to(d), bias.to(d), a2=x1.to(d), conv=dict(stride=1), row_bias=rb.to(d), rows_per_img=h * w,
-                   residual=res.to(d))
-    check(out, ref, name='conv concat')
+    for tile in (0, 6, 7, 8, 9, 10, 11, 12):
+        out = ops.gemm(x0.to(d), wt.to(d), bias.to(d), a2=x1.to(d), conv=dict(stride=1), row_bias=rb.to(d), rows_per_img=h * w,
+                       residual=res.to(d), tile=tile)
+        check(out, ref, name=f'conv concat tile{tile}')
 
 
 def test_conv1x1_two_sources():

@@ -41,6 +41,7 @@ def main():
     ap.add_argument('--tiles', default='0')
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--only', default='')
+    ap.add_argument('--split', type=int, default=0, help='force split-K factor (0 = auto)')
     args = ap.parse_args()
     tiles = [int(t) for t in args.tiles.split(',')]
     d = torch.device('cuda:0')
@@ -55,7 +56,7 @@ def main():
             w = (torch.randn(n, k, generator=g) * k ** -0.5).half().to(d)
             bias = torch.randn(n).to(d)
             fl = 2.0 * m * n * k
-            call = lambda t: ops.gemm(a, w, bias, tile=t)
+            call = lambda t, it=0: ops.gemm(a, w, bias, tile=t, time_iters=it, split_k=args.split)
         else:
             nb, h, wd, cin, cout, stride, ups = prm
             a = torch.randn(nb, h, wd, cin, generator=g).half().to(d)
@@ -63,19 +64,10 @@ def main():
             bias = torch.randn(cout).to(d)
             ho = (h * (2 if ups else 1)) // stride
             fl = 2.0 * nb * ho * ho * cout * 9 * cin
-            call = lambda t: ops.gemm(a, w, bias, conv=dict(stride=stride, upsample=ups), tile=t)
+            call = lambda t, it=0: ops.gemm(a, w, bias, conv=dict(stride=stride, upsample=ups), tile=t, time_iters=it, split_k=args.split)
         row = f'{name:28s} {fl / 1e9:8.2f} '
         for t in tiles:
-            for _ in range(3):
-                call(t)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(args.iters):
-                call(t)
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / args.iters
+            us = call(t, args.iters) * 1e3   # timed inside the library: back-to-back launches, HIP events
             row += f'{us:9.1f} {fl / us / 1e6:7.1f} '
         print(row, flush=True)
 
