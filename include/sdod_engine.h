@@ -10,11 +10,14 @@
  *
  * I/O slots (device memory owned by the graph; sdod_graph_io() returns pointer + size):
  *   UNET          in0 x    fp32 NCHW [B][4][H][W]        (context.cpp:214  x = unet.allocate_input(0))
- *                 in1 temb fp16 [B][4*model_ch]          (context.cpp:215  t = unet.allocate_input(1))
+ *                 in1 temb fp16 [B][E]                   (context.cpp:215  t = unet.allocate_input(1)); E = width of the
+ *                                                        TEMB graph's output: the time-MLP output pushed through every
+ *                                                        ResBlock's emb_layers projection (all of it depends on t only,
+ *                                                        so it is computed once per step and cached like context.cpp:276-278)
  *                 in2 ctx  fp16 [B][77][ctx_dim]         (context.cpp:216  p_cond / p_uncond = input(2))
  *                 out0 e   fp16 NHWC [B][H][W][4]        (context.cpp:218  e = unet.allocate_output(0))
  *   TEMB          in0 t    fp32 [B]                      (model time, dpm_solver.cpp:115)
- *                 out0     fp16 [B][4*model_ch]          (context.cpp:257-278: sinusoid + temb graph)
+ *                 out0     fp16 [B][E]                   (context.cpp:257-278: sinusoid + temb graph, + emb_layers)
  *   TEXT_ENCODER  in0 ids  int32 [B][77]                 (context.cpp:207 tokens)
  *                 out0     fp16 [B][77][ctx_dim]         (context.cpp:208 p)
  *   VAE_DECODER   in0 z    fp32 NCHW [B][4][H][W]        (context.cpp:220 y)
@@ -72,8 +75,11 @@ SDOD_API int sdod_graph_load_file(void* graph, const char* path, const char* pre
 /* checks that every parameter is set, sizes and allocates the activation arena, builds the launch list */
 SDOD_API int sdod_graph_finalize(void* graph);
 SDOD_API int sdod_graph_io(void* graph, int is_output, int index, void** device_ptr, size_t* bytes);
-/* run once on `stream`.  use_hip_graph != 0: the launch list is captured on first use and replayed */
-SDOD_API int sdod_graph_execute(void* graph, void* stream, int use_hip_graph);
+/* run once on `stream`.  flags bit 0 (SDOD_EXEC_HIP_GRAPH): the launch list is captured on first use and replayed as one
+ * hipGraph; bit 1 (SDOD_EXEC_STATIC_UNCHANGED): the graph's static inputs (UNET in2, the text context, which is constant
+ * over a sampler run) have not changed since the previous execute, so the launches depending only on them are skipped */
+enum sdod_exec_flags { SDOD_EXEC_HIP_GRAPH = 1, SDOD_EXEC_STATIC_UNCHANGED = 2 };
+SDOD_API int sdod_graph_execute(void* graph, void* stream, int flags);
 /* launch list introspection + per-launch timing (HIP events on `stream`, eager, averaged over iters runs after one
  * warm-up): label = kernel family/variant ("gemm_t2", "gemm_t3_splitk", "attn_d40", "group_norm", ...), flops/bytes =
  * algorithmic work of that launch.  bench.py derives its roofline block from these. */

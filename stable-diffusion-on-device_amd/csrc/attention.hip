@@ -175,40 +175,59 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
             }
         }
 
-        // ---- online softmax; lane owns query qrow[a], keys t*64 + c*16 + 4g + r
+        // ---- online softmax; lane owns query qrow[a], keys t*64 + c*16 + 4g + r.
+        // VALU budget matters here (at d=40 the MFMAs of a tile take ~450 cycles, a naive softmax 3x that): the row max is
+        // taken on the RAW scores (scale > 0), exp2(s*c - m*c) is one fma + one v_exp, masking code only runs for tiles that
+        // contain masked keys (the last ragged tile / the causal diagonal), sums and scaling use packed fp32 pairs.
+        const bool need_mask = (t * KT + KT > p.Lk) || (p.causal && (t * KT + KT - 1 > q_block + wave * (16 * QT)));
         f16x8 pf[QT][2];
 #pragma unroll
         for (int a = 0; a < QT; ++a) {
-            float mx = -1e30f;
+            if (need_mask) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = t * KT + c * 16 + g * 4 + r;
-                    float v = s[a][c][r] * p.scale_log2;
-                    const bool masked = (key >= p.Lk) || (p.causal && key > qrow[a]);
-                    v = masked ? -1e30f : v;
-                    s[a][c][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = t * KT + c * 16 + g * 4 + r;
+                        const bool masked = (key >= p.Lk) | (p.causal & (key > qrow[a]));
+                        s[a][c][r] = masked ? -1e30f : s[a][c][r];
+                    }
+            }
+            f32x4 m4 = s[a][0];
+#pragma unroll
+            for (int c = 1; c < 4; ++c) {
+                m4[0] = fmaxf(m4[0], s[a][c][0]); m4[1] = fmaxf(m4[1], s[a][c][1]);
+                m4[2] = fmaxf(m4[2], s[a][c][2]); m4[3] = fmaxf(m4[3], s[a][c][3]);
+            }
+            float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[a], mx);
+            const float m_new = fmaxf(m_run[a], mx * p.scale_log2); // running max in scaled (log2) units
             const float alpha = __builtin_amdgcn_exp2f(m_run[a] - m_new);
             m_run[a] = m_new;
-            float rs = 0.f;
+            f32x2 rs2 = {0.f, 0.f};
+            const f32x2 sc2 = {p.scale_log2, p.scale_log2};
+            const f32x2 nm2 = {-m_new, -m_new};
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(s[a][c][r] - m_new);
-                    s[a][c][r] = e;
-                    rs += e;
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    f32x2 v = {s[a][c][2 * h2], s[a][c][2 * h2 + 1]};
+                    v = v * sc2 + nm2; // packed fma
+                    v[0] = __builtin_amdgcn_exp2f(v[0]);
+                    v[1] = __builtin_amdgcn_exp2f(v[1]);
+                    rs2 += v;
+                    s[a][c][2 * h2] = v[0];
+                    s[a][c][2 * h2 + 1] = v[1];
                 }
-            l_run[a] = l_run[a] * alpha + rs;
+            }
+            l_run[a] = l_run[a] * alpha + (rs2[0] + rs2[1]);
+            const f32x2 al2 = {alpha, alpha};
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                o[a][dt][0] *= alpha; o[a][dt][1] *= alpha; o[a][dt][2] *= alpha; o[a][dt][3] *= alpha;
+                f32x2 lo = {o[a][dt][0], o[a][dt][1]}, hi = {o[a][dt][2], o[a][dt][3]};
+                lo *= al2; hi *= al2;
+                o[a][dt][0] = lo[0]; o[a][dt][1] = lo[1]; o[a][dt][2] = hi[0]; o[a][dt][3] = hi[1];
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {

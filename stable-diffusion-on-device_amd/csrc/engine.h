@@ -63,7 +63,9 @@ public:
     void set_param(const std::string& name, const void* data, int dtype, const int64_t* shape, int ndim);
     void load_file(const std::string& path, const std::string& prefix);
     void finalize();
-    void execute(hipStream_t st, bool use_hip_graph);
+    // skip_static: the inputs marked "static across a sampler run" (UNet: the text context) are unchanged since the
+    // previous execute(), so the launches that depend only on them (all cross-attention K/V projections) are skipped
+    void execute(hipStream_t st, bool use_hip_graph, bool skip_static = false);
     IoSlot io(bool output, int index) const;
     void stats(size_t* wbytes, size_t* abytes, int* launches, double* flops) const;
 
@@ -117,6 +119,8 @@ private:
         std::string detail;  // shape, for the per-layer profile table (tools/unet_profile.py)
     };
     std::vector<Op> ops_;
+    std::vector<Op> static_ops_; // depend only on static inputs; run by execute() unless skip_static
+    bool to_static_ = false;     // emitters append to static_ops_ while set
     double flops_ = 0;
     hipGraphExec_t graph_exec_ = nullptr;
     hipGraph_t hip_graph_ = nullptr;
@@ -155,13 +159,18 @@ private:
 
     // ---- model blocks
     Act res_block(const std::string& pfx, const Act& x, const Act* x2, int cout, const f16* emb_all, int emb_ld, int& emb_off);
+    std::vector<Op>& sink() { return to_static_ ? static_ops_ : ops_; }
     Act spatial_transformer(const std::string& pfx, const Act& x, const Act& ctx);
     Act vae_res_block(const std::string& pfx, const Act& x, int cout);
     Act vae_attn_block(const std::string& pfx, const Act& x);
     int emb_total_ = 0; // sum of ResBlock output channels (set by the DECLARE pass)
+    int kv_total_ = 0;  // sum over SpatialTransformers of 2*C: width of the batched cross-attention K/V matrix
+    f16* kv_all_ = nullptr; // [B*context_len][kv_total_], persistent (not arena memory)
+    int kv_off_ = 0;
+    std::vector<std::pair<std::string, int>> unet_res_blocks() const; // (prefix, cout) in declaration order
     const char* group_base(const std::string& group) const;
     void emit(std::function<void(hipStream_t)> fn, const char* label = "elementwise", double flops = 0, double bytes = 0) {
-        if (mode_ == REAL) ops_.push_back(Op{std::move(fn), label, flops, bytes, ""});
+        if (mode_ == REAL) sink().push_back(Op{std::move(fn), label, flops, bytes, ""});
     }
 
 public:

@@ -57,6 +57,7 @@ Graph::~Graph() {
     (void)hipFree(arena_base_);
     (void)hipFree(ws_);
     (void)hipFree(gn_ws_);
+    (void)hipFree(kv_all_);
 }
 
 // ------------------------------------------------------------------------------------------ parameters
@@ -355,7 +356,11 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
         for (int t : kCandidates) {
             sdod_gemm_desc c = d;
             c.tile = t;
-            ws_need_ = std::max(ws_need_, sdod_gemm_workspace_bytes(&c));
+            c.split_k = 0;
+            int tt = 0, sp = 1;
+            (void)sdod_gemm_plan(&c, &tt, &sp);
+            c.split_k = sp > 1 ? std::min(64, sp * 2) : 1;
+            if (c.split_k > 1 && d.N % 4 == 0) ws_need_ = std::max(ws_need_, sdod_gemm_workspace_bytes(&c));
         }
     }
     ws_need_ = std::max(ws_need_, sdod_gemm_workspace_bytes(&d));
@@ -368,19 +373,36 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
         if (it == tune_cache().end()) {
             int best = 0;
             float best_ms = 1e30f;
+            // candidates: every tile x {heuristic split-K, half, double, none (one launch instead of two)}
+            const int KT = d.K / 64;
             for (int t : kCandidates) {
-                sdod_gemm_desc c = d;
-                c.tile = t;
-                float ms = 0.f;
-                if (sdod_gemm_time(&c, nullptr, 4, &ms) != 0) continue;
-                if (ms < best_ms) {
-                    best_ms = ms;
-                    best = t;
+                sdod_gemm_desc h = d;
+                h.tile = t;
+                h.split_k = 0;
+                int tt = 0, sp = 1;
+                (void)sdod_gemm_plan(&h, &tt, &sp);
+                int tried[4] = {sp, 1, sp / 2, sp > 1 ? sp * 2 : 0};
+                for (int k = 0; k < 4; ++k) {
+                    const int want = tried[k];
+                    bool dup = want < 1 || want > 64 || (want > 1 && KT / want < 2) || (want > 1 && d.N % 4 != 0);
+                    for (int j = 0; j < k && !dup; ++j) dup = tried[j] == want;
+                    if (dup) continue;
+                    sdod_gemm_desc c = d;
+                    c.tile = t;
+                    c.split_k = want;
+                    if (sdod_gemm_workspace_bytes(&c) > ws_bytes_) continue;
+                    float ms = 0.f;
+                    if (sdod_gemm_time(&c, nullptr, 4, &ms) != 0) continue;
+                    if (ms < best_ms) {
+                        best_ms = ms;
+                        best = t + 1000 * want;
+                    }
                 }
             }
             it = tune_cache().emplace(key, best).first;
         }
-        d.tile = it->second;
+        d.tile = it->second % 1000;
+        d.split_k = it->second / 1000;
     }
     const double fl = 2.0 * d.M * d.N * d.K;
     flops_ += fl;
@@ -396,7 +418,7 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
     std::string detail = (d.a_mode == SDOD_A_ROWS ? std::string("rows") : "conv" + std::to_string(d.ksize) + (d.upsample ? "u" : "") +
                                                                           (d.stride == 2 ? "s2" : "") + (d.c1 ? "+cat" : "")) +
                          " M" + std::to_string(d.M) + " N" + std::to_string(d.N) + " K" + std::to_string(d.K) + " x" + std::to_string(splits);
-    ops_.push_back(Op{[d](hipStream_t st) { check_rc(sdod_gemm_f16(&d, st)); }, label, fl, by, detail});
+    sink().push_back(Op{[d](hipStream_t st) { check_rc(sdod_gemm_f16(&d, st)); }, label, fl, by, detail});
 }
 
 void Graph::linear_raw(const f16* x, int rows, int K, const f16* w, int ldw, int N, f16* out, const GemmOpt& o) {
@@ -515,16 +537,21 @@ void Graph::finalize() {
     SDOD_HIP_CHECK(hipMalloc((void**)&arena_base_, arena_cap_));
     SDOD_HIP_CHECK(hipMalloc((void**)&ws_, ws_bytes_));
     SDOD_HIP_CHECK(hipMalloc((void**)&gn_ws_, gn_ws_bytes_));
+    if (kind_ == SDOD_GRAPH_UNET && kv_total_ > 0)
+        SDOD_HIP_CHECK(hipMalloc((void**)&kv_all_, (size_t)batch_ * cfg_.context_len * kv_total_ * sizeof(f16)));
     mode_ = REAL;
     arena_reset();
     ops_.clear();
+    static_ops_.clear();
     flops_ = 0;
     build();
     finalized_ = true;
 }
 
-void Graph::execute(hipStream_t st, bool use_hip_graph) {
+void Graph::execute(hipStream_t st, bool use_hip_graph, bool skip_static) {
     SDOD_REQUIRE(finalized_, "graph not finalized");
+    if (!skip_static || eager_runs_ == 0)
+        for (auto& op : static_ops_) op.fn(st);
     if (!use_hip_graph || eager_runs_ == 0) {
         // the first run is always eager: it sets kernel attributes (dynamic LDS sizes), which must not happen in capture
         for (auto& op : ops_) op.fn(st);
@@ -579,7 +606,7 @@ void Graph::profile(hipStream_t st, int iters, float* ms, int n) {
 void Graph::stats(size_t* wbytes, size_t* abytes, int* launches, double* flops) const {
     if (wbytes) *wbytes = weight_bytes_;
     if (abytes) *abytes = arena_cap_;
-    if (launches) *launches = (int)ops_.size();
+    if (launches) *launches = (int)ops_.size();  // per evaluation; static_ops_ run once per static-input change
     if (flops) *flops = flops_;
 }
 
@@ -673,7 +700,7 @@ extern "C" int sdod_graph_io(void* graph, int is_output, int index, void** devic
 extern "C" int sdod_graph_execute(void* graph, void* stream, int use_hip_graph) {
     SDOD_TRY
     SDOD_REQUIRE(graph != nullptr, "null graph");
-    static_cast<Graph*>(graph)->execute((hipStream_t)stream, use_hip_graph != 0);
+    static_cast<Graph*>(graph)->execute((hipStream_t)stream, (use_hip_graph & 1) != 0, (use_hip_graph & 2) != 0);
     return 0;
     SDOD_CATCH
 }

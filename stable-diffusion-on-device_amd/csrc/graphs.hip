@@ -30,11 +30,8 @@ const char* Graph::group_base(const std::string& group) const {
 // ------------------------------------------------------------------------------------------------ UNet
 Act Graph::res_block(const std::string& pfx, const Act& x, const Act* x2, int cout, const f16* emb_all, int emb_ld, int& emb_off) {
     const int cin = x.c + (x2 ? x2->c : 0);
-    const int emb_ch = 4 * cfg_.model_channels;
     const int n1w = P(pfx + ".in_layers.0.weight", {cin}, PK_VEC), n1b = P(pfx + ".in_layers.0.bias", {cin}, PK_VEC);
     const int c1w = P(pfx + ".in_layers.2.weight", {cout, cin, 3, 3}, PK_CONV3), c1b = P(pfx + ".in_layers.2.bias", {cout}, PK_VEC);
-    P(pfx + ".emb_layers.1.weight", {cout, emb_ch}, PK_LINEAR, "emb_w");
-    P(pfx + ".emb_layers.1.bias", {cout}, PK_VEC, "emb_b");
     const int n2w = P(pfx + ".out_layers.0.weight", {cout}, PK_VEC), n2b = P(pfx + ".out_layers.0.bias", {cout}, PK_VEC);
     const int c2w = P(pfx + ".out_layers.3.weight", {cout, cout, 3, 3}, PK_CONV3), c2b = P(pfx + ".out_layers.3.bias", {cout}, PK_VEC);
     int skw = -1, skb = -1;
@@ -89,9 +86,12 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     const int o1w = P(tb + ".attn1.to_out.0.weight", {C, C}, PK_LINEAR), o1b = P(tb + ".attn1.to_out.0.bias", {C}, PK_VEC);
     const int l2w = P(tb + ".norm2.weight", {C}, PK_VEC), l2b = P(tb + ".norm2.bias", {C}, PK_VEC);
     const int q2w = P(tb + ".attn2.to_q.weight", {C, C}, PK_LINEAR);
-    const std::string gkv = tb + ".attn2.kv";
-    P(tb + ".attn2.to_k.weight", {C, cd}, PK_LINEAR, gkv);
-    P(tb + ".attn2.to_v.weight", {C, cd}, PK_LINEAR, gkv);
+    // every layer's to_k|to_v lives in ONE group: the context projections of all 16 transformers are a single GEMM that
+    // runs once per prompt (the context is constant over the sampler run), see build_unet()
+    P(tb + ".attn2.to_k.weight", {C, cd}, PK_LINEAR, "attn2_kv_all");
+    P(tb + ".attn2.to_v.weight", {C, cd}, PK_LINEAR, "attn2_kv_all");
+    const int my_kv = kv_off_;
+    kv_off_ += 2 * C;
     const int o2w = P(tb + ".attn2.to_out.0.weight", {C, C}, PK_LINEAR), o2b = P(tb + ".attn2.to_out.0.bias", {C}, PK_VEC);
     const int l3w = P(tb + ".norm3.weight", {C}, PK_VEC), l3b = P(tb + ".norm3.bias", {C}, PK_VEC);
     const int f1w = P(tb + ".ff.net.0.proj.weight", {8 * C, C}, PK_LINEAR), f1b = P(tb + ".ff.net.0.proj.bias", {8 * C}, PK_VEC);
@@ -119,12 +119,11 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     f16* q2 = alloc((size_t)rows * C);
     linear(n2.p, rows, C, q2w, C, q2, GemmOpt{});
     release(n2);
-    const int crow = ctx.rows(), Lk = ctx.w;
-    f16* kv = alloc((size_t)crow * 2 * C);
-    linear_raw(ctx.p, crow, cd, reinterpret_cast<const f16*>(group_base(gkv)), cd, 2 * C, kv, GemmOpt{});
+    const int Lk = ctx.w;
+    const f16* kv = kv_all_ + my_kv;
     f16* a2 = alloc((size_t)rows * C);
-    attention(q2, kv, kv + C, a2, B, heads, L, Lk, d, C, 2 * C, 2 * C, C, false);
-    release(q2); release(kv);
+    attention(q2, kv, kv + C, a2, B, heads, L, Lk, d, C, kv_total_, kv_total_, C, false);
+    release(q2);
     Act t2 = act(B, 1, L, C);
     { GemmOpt o; o.bias = o2b; o.residual = t1.p; linear(a2, rows, C, o2w, C, t2.p, o); }
     release(a2); release(t1);
@@ -151,25 +150,30 @@ void Graph::build_unet() {
     SDOD_REQUIRE(LC * 9 <= 64, "latent_channels too large for the small-Cin path");
     const int mult[4] = {1, 2, 4, 4};
 
+    if (mode_ != DECLARE) { // widths fixed by the DECLARE pass
+        int tot = 0;
+        for (auto& rb : unet_res_blocks()) tot += rb.second;
+        emb_total_ = tot;
+    }
     float* x_in = (float*)io_alloc(inputs_, (size_t)B * LC * H * Wd * sizeof(float));
-    f16* temb_in = (f16*)io_alloc(inputs_, (size_t)B * EC * sizeof(f16));
+    f16* temb_in = (f16*)io_alloc(inputs_, (size_t)B * std::max(emb_total_, 1) * sizeof(f16));
     f16* ctx_in = (f16*)io_alloc(inputs_, (size_t)B * CL * cd * sizeof(f16));
     f16* e_out = (f16*)io_alloc(outputs_, (size_t)B * H * Wd * LC * sizeof(f16));
     Act ctx;
     ctx.p = ctx_in; ctx.n = B; ctx.h = 1; ctx.w = CL; ctx.c = cd;
-
-    // time embedding -> all ResBlock projections in one GEMM
-    f16* st_emb = alloc((size_t)B * EC);
-    emit([=](hipStream_t st) { check_rc2(sdod_act_f16(temb_in, st_emb, (size_t)B * EC, SDOD_ACT_SILU, st)); });
+    (void)EC;
+    // the time conditioning arrives already projected for every ResBlock (TEMB graph): row b, columns [off, off+cout)
     const int emb_ld = emb_total_;
-    f16* emb_all = nullptr;
-    if (mode_ != DECLARE) {
-        emb_all = alloc((size_t)B * emb_ld);
-        GemmOpt o;
-        o.bias_raw = reinterpret_cast<const float*>(group_base("emb_b"));
-        linear_raw(st_emb, B, EC, reinterpret_cast<const f16*>(group_base("emb_w")), EC, emb_ld, emb_all, o);
-    }
+    const f16* emb_all = temb_in;
     int emb_off = 0;
+    kv_off_ = 0;
+    // cross-attention K/V of ALL transformers: one GEMM on the text context, re-run only when the context changes
+    if (mode_ != DECLARE && kv_total_ > 0) {
+        to_static_ = true;
+        linear_raw(ctx_in, B * CL, cd, reinterpret_cast<const f16*>(group_base("attn2_kv_all")), cd, kv_total_,
+                   mode_ == REAL ? kv_all_ : ctx_in /* placeholder during the sizing pass */, GemmOpt{});
+        to_static_ = false;
+    }
 
     // input conv (Cin = 4): im2col to K = 64, then the GEMM
     const int ciw = P("input_blocks.0.0.weight", {MC, LC, 3, 3}, PK_CONV3_SMALL), cib = P("input_blocks.0.0.bias", {MC}, PK_VEC);
@@ -248,25 +252,56 @@ void Graph::build_unet() {
     release(h);
     { GemmOpt o; o.bias = cb; o.out = e_out; conv(g, nullptr, cw, LC, 3, 1, false, o); }
     release(g);
-    release(st_emb);
-    if (emb_all) release(emb_all);
-    if (mode_ == DECLARE) emb_total_ = emb_off;
-    else if (emb_off != emb_total_) throw Error(INTERNAL_ERROR, "time-embedding projection bookkeeping mismatch");
+    if (mode_ == DECLARE) kv_total_ = kv_off_;
+    else if (emb_off != emb_total_ || kv_off_ != kv_total_) throw Error(INTERNAL_ERROR, "UNet conditioning bookkeeping mismatch");
+}
+
+// (prefix, cout) of every ResBlock in the order build_unet() visits them: the column layout of the TEMB graph's output
+std::vector<std::pair<std::string, int>> Graph::unet_res_blocks() const {
+    std::vector<std::pair<std::string, int>> v;
+    const int MC = cfg_.model_channels;
+    const int mult[4] = {1, 2, 4, 4};
+    int idx = 1;
+    for (int level = 0; level < 4; ++level) {
+        for (int i = 0; i < 2; ++i) v.emplace_back("input_blocks." + std::to_string(idx++) + ".0", mult[level] * MC);
+        if (level != 3) ++idx;
+    }
+    v.emplace_back("middle_block.0", 4 * MC);
+    v.emplace_back("middle_block.2", 4 * MC);
+    int oidx = 0;
+    for (int level = 3; level >= 0; --level)
+        for (int i = 0; i < 3; ++i) v.emplace_back("output_blocks." + std::to_string(oidx++) + ".0", mult[level] * MC);
+    return v;
 }
 
 // ------------------------------------------------------------------------------------------------ temb
 void Graph::build_temb() {
+    // context.cpp:257-278 (sinusoid -> time MLP), extended by everything else that depends on t only: SiLU and the
+    // emb_layers projection of all 22 ResBlocks, as ONE GEMM.  Output row = what the UNet graph consumes as in1.
     const int B = batch_, MC = cfg_.model_channels, EC = 4 * MC;
+    const auto blocks = unet_res_blocks();
+    int total = 0;
+    for (auto& rb : blocks) total += rb.second;
     float* t_in = (float*)io_alloc(inputs_, (size_t)B * sizeof(float));
-    f16* out = (f16*)io_alloc(outputs_, (size_t)B * EC * sizeof(f16));
+    f16* out = (f16*)io_alloc(outputs_, (size_t)B * total * sizeof(f16));
     const int w0 = P("time_embed.0.weight", {EC, MC}, PK_LINEAR), b0 = P("time_embed.0.bias", {EC}, PK_VEC);
     const int w2 = P("time_embed.2.weight", {EC, EC}, PK_LINEAR), b2 = P("time_embed.2.bias", {EC}, PK_VEC);
+    for (auto& rb : blocks) {
+        P(rb.first + ".emb_layers.1.weight", {rb.second, EC}, PK_LINEAR, "emb_w");
+        P(rb.first + ".emb_layers.1.bias", {rb.second}, PK_VEC, "emb_b");
+    }
     f16* feat = alloc((size_t)B * MC);
     emit([=](hipStream_t st) { check_rc2(sdod_timestep_features_f16(t_in, feat, B, MC, st)); });
     f16* hmid = alloc((size_t)B * EC);
     { GemmOpt o; o.bias = b0; o.act = SDOD_ACT_SILU; linear(feat, B, MC, w0, EC, hmid, o); }
-    { GemmOpt o; o.bias = b2; linear(hmid, B, EC, w2, EC, out, o); }
-    release(feat); release(hmid);
+    f16* emb = alloc((size_t)B * EC);
+    { GemmOpt o; o.bias = b2; o.act = SDOD_ACT_SILU; linear(hmid, B, EC, w2, EC, emb, o); } // SiLU(time_embed(t)): emb_layers.0
+    if (mode_ != DECLARE) {
+        GemmOpt o;
+        o.bias_raw = reinterpret_cast<const float*>(group_base("emb_b"));
+        linear_raw(emb, B, EC, reinterpret_cast<const f16*>(group_base("emb_w")), EC, total, out, o);
+    }
+    release(feat); release(hmid); release(emb);
 }
 
 // ------------------------------------------------------------------------------------------------ VAE

@@ -138,8 +138,8 @@ void Context::generate(const std::string& prompt, float guidance, unsigned char*
     const int C = (int)latent_channels_, HW = (int)(latent_spatial_ * latent_spatial_);
     const size_t lat = (size_t)C * HW;
     const size_t ctx_bytes = (size_t)cfg_.context_len * cfg_.context_dim * sizeof(f16);
-    const size_t temb_row = (size_t)4 * cfg_.model_channels * sizeof(f16);
     const IoSlot ux = unet_->io(false, 0), ut = unet_->io(false, 1), uc = unet_->io(false, 2), ue = unet_->io(true, 0);
+    const size_t temb_row = ut.bytes / 2; // one row of projected time conditioning (two batch rows in the UNet slot)
 
     Timer t;
     // row 0 = conditional, row 1 = unconditional
@@ -160,7 +160,7 @@ void Context::generate(const std::string& prompt, float guidance, unsigned char*
         const char* te = reinterpret_cast<const char*>(temb_cache_) + step * temb_row;
         SDOD_HIP_CHECK(hipMemcpyAsync(ut.ptr, te, temb_row, hipMemcpyDeviceToDevice, stream_));
         SDOD_HIP_CHECK(hipMemcpyAsync(static_cast<char*>(ut.ptr) + temb_row, te, temb_row, hipMemcpyDeviceToDevice, stream_));
-        unet_->execute(stream_, true);
+        unet_->execute(stream_, true, /*skip_static=*/step > 0); // the text context only changes between images
         // e = g*e_cond + (1-g)*e_uncond (context.cpp:359-373); g == 1 keeps e_cond only
         rc_check(sdod_cfg_combine(ue.ptr, e_dev_, 1, C, HW, guidance, /*uncond_first=*/0, /*mode=*/0, stream_));
         const DpmSolver::StepCoef k = solver_->coef(step);

@@ -198,8 +198,125 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnP p) {
     }
 }
 
+// Small feature maps (the 8x8 / 16x16 / 32x32 levels: 2/3 of the UNet's GroupNorms): ONE launch.  A workgroup owns all
+// pixels of image n for a channel set of `sw` channels (whole groups, 16-byte aligned: sw = lcm(C/G, 8)); the slab is
+// read once into LDS, statistics are an exact two-pass reduction over LDS, then normalise + SiLU + store.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_small_kernel(const GnP p, int sw) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* slab = reinterpret_cast<T*>(smem_raw);                               // [HW][sw]
+    float* sc = reinterpret_cast<float*>(smem_raw + (size_t)p.HW * sw * sizeof(T)); // [sw] scale
+    float* sh = sc + sw;                                                    // [sw] shift
+    float* red = sh + sw;                                                   // [4 waves][4 groups][2], then the group table
+    const int n = blockIdx.y;
+    const int cbase = blockIdx.x * sw;
+    const int cps = sw / 8;
+    const int total = p.HW * cps;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < total; i += 256) {
+        const int pix = i / cps, cc = i - pix * cps;
+        const T* src = gn_src<T>(p, n, pix, cbase + cc * 8);
+        if (sizeof(T) == 2) {
+            *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(slab) + (size_t)pix * sw + cc * 8) = ldg8(reinterpret_cast<const f16*>(src));
+        } else {
+            float v[8];
+            Chunk8<T>::load(src, v);
+            Chunk8<T>::store(slab + (size_t)pix * sw + cc * 8, v);
+        }
+    }
+    // group of every channel of the set (sw small divisions instead of one per element)
+    unsigned char* gidx = reinterpret_cast<unsigned char*>(red + 64);
+    for (int c = tid; c < sw; c += 256) gidx[c] = (unsigned char)(c / p.Cg);
+    __syncthreads();
+    const int ng = sw / p.Cg; // <= 4 for every SD channel count (asserted on the host)
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, shf[4];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) shf[gi] = gi < ng ? (float)slab[gi * p.Cg] : 0.f; // pilot shift: first element of the group
+    for (int i = tid; i < total; i += 256) {
+        const int pix = i / cps, cc = i - pix * cps;
+        float v[8];
+        Chunk8<T>::load(slab + (size_t)pix * sw + cc * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = gidx[cc * 8 + e];
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                const float d = g == gi ? v[e] - shf[gi] : 0.f;
+                s1[gi] += d;
+                s2[gi] += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s1[gi] += __shfl_xor(s1[gi], o);
+            s2[gi] += __shfl_xor(s2[gi], o);
+        }
+        if (lane == 0) {
+            red[(wave * 4 + gi) * 2 + 0] = s1[gi];
+            red[(wave * 4 + gi) * 2 + 1] = s2[gi];
+        }
+    }
+    __syncthreads();
+    const float inv_cnt = 1.0f / ((float)p.HW * (float)p.Cg);
+    for (int c = tid; c < sw; c += 256) {
+        const int gi = gidx[c];
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            a += red[(w * 4 + gi) * 2 + 0];
+            b += red[(w * 4 + gi) * 2 + 1];
+        }
+        const float md = a * inv_cnt;
+        float var = b * inv_cnt - md * md;
+        var = var < 0.f ? 0.f : var;
+        const float mean = (float)slab[gi * p.Cg] + md;
+        const float rstd = 1.0f / sqrtf(var + p.eps);
+        const int ch = cbase + c;
+        const float w = p.w ? p.w[ch] : 1.0f, bb = p.b ? p.b[ch] : 0.0f;
+        sc[c] = rstd * w;
+        sh[c] = bb - mean * rstd * w;
+    }
+    __syncthreads();
+    T* yout = reinterpret_cast<T*>(p.y) + (size_t)n * p.HW * p.C + cbase;
+    for (int i = tid; i < total; i += 256) {
+        const int pix = i / cps, cc = i - pix * cps;
+        float v[8];
+        Chunk8<T>::load(slab + (size_t)pix * sw + cc * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = v[e] * sc[cc * 8 + e] + sh[cc * 8 + e];
+            if (p.silu) f = silu_f(f);
+            v[e] = f;
+        }
+        Chunk8<T>::store(yout + (size_t)pix * p.C + cc * 8, v);
+    }
+}
+
+static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
+
+template <typename T>
+bool gn_try_small(GnP& p, hipStream_t st) {
+    const int sw = p.Cg / gcd_i(p.Cg, 8) * 8; // lcm(Cg, 8)
+    if (p.C % sw != 0) return false;
+    const size_t smem = (size_t)p.HW * sw * sizeof(T) + ((size_t)2 * sw + 64) * sizeof(float) + (size_t)sw;
+    if (p.HW > 256 || sw / p.Cg > 4 || smem > 96 * 1024) return false;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SDOD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           96 * 1024 + 4096));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gn_small_kernel<T>), dim3(p.C / sw, p.N), dim3(256), smem, st, p, sw);
+    SDOD_HIP_CHECK(hipGetLastError());
+    return true;
+}
+
 template <typename T>
 void gn_launch(GnP& p, hipStream_t st) {
+    if (gn_try_small<T>(p, st)) return;
     const int cp = p.C / 8;
     p.npass = (cp + 255) / 256;
     SDOD_REQUIRE(p.npass <= 2 && cp % p.npass == 0, "unsupported channel count for GroupNorm");

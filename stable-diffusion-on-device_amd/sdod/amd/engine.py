@@ -134,9 +134,10 @@ class Graph:
         assert numel * torch.empty((), dtype=dtype).element_size() == nbytes, (shape, dtype, nbytes)
         return device_view(ptr, shape, dtype, self.device)
 
-    def execute(self, use_hip_graph=False):
-        check(self._lib.sdod_graph_execute(self._h, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream),
-                                           1 if use_hip_graph else 0))
+    def execute(self, use_hip_graph=False, static_unchanged=False):
+        """static_unchanged: the static inputs (UNet: text context) are the same as in the previous execute()"""
+        flags = (1 if use_hip_graph else 0) | (2 if static_unchanged else 0)
+        check(self._lib.sdod_graph_execute(self._h, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), flags))
 
     def op_table(self):
         """[(label, flops, bytes)] for every launch of the graph"""
@@ -176,7 +177,8 @@ class UNet(Graph):
         super().finalize()
         c, b = self.cfg, self.batch
         self.x = self.io_tensor(False, 0, (b, c.latent_channels, c.latent_h, c.latent_w), torch.float32)
-        self.temb = self.io_tensor(False, 1, (b, 4 * c.model_channels), torch.float16)
+        self.temb_width = self._io(False, 1)[1] // (2 * b)       # projected time conditioning (TEMB graph output width)
+        self.temb = self.io_tensor(False, 1, (b, self.temb_width), torch.float16)
         self.ctx = self.io_tensor(False, 2, (b, c.context_len, c.context_dim), torch.float16)
         self.eps = self.io_tensor(True, 0, (b, c.latent_h, c.latent_w, c.latent_channels), torch.float16)
         return self
@@ -189,7 +191,8 @@ class Temb(Graph):
     def finalize(self):
         super().finalize()
         self.t = self.io_tensor(False, 0, (self.batch,), torch.float32)
-        self.out = self.io_tensor(True, 0, (self.batch, 4 * self.cfg.model_channels), torch.float16)
+        self.width = self._io(True, 0)[1] // (2 * self.batch)
+        self.out = self.io_tensor(True, 0, (self.batch, self.width), torch.float16)
         return self
 
 

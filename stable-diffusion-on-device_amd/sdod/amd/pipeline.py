@@ -37,6 +37,7 @@ class Txt2Img:
             self._load(g, key, stem)
             g.finalize()
         self._temb_cache = {}
+        self._ctx_fresh = True
 
     def _load(self, g, key, stem):
         if self._sd is not None:
@@ -56,7 +57,8 @@ class Txt2Img:
         return self.encode_tokens(self.tokenizer.encode(negative), self.tokenizer.encode(prompt))
 
     def time_embeddings(self, times):
-        """[len(times), 1280] fp16 for model times `times` (cached per schedule, as context.cpp:257-278 does)"""
+        """[len(times), E] fp16: time-MLP output projected for every ResBlock, for model times `times` (cached per
+        schedule, as context.cpp:257-278 does)"""
         key = tuple(float(t) for t in times)
         if key not in self._temb_cache:
             g = self._temb_graphs.get(len(key))
@@ -75,13 +77,15 @@ class Txt2Img:
         n = self.n
         self.unet.ctx[:n].copy_(ctx2[0:1].expand(n, -1, -1))
         self.unet.ctx[n:].copy_(ctx2[1:2].expand(n, -1, -1))
+        self._ctx_fresh = True     # the next UNet execute must redo the cross-attention K/V projections
 
     def _eps(self, x, temb_row, guidance, mode):
         """x: fp32 [n,4,H,W]; returns guided eps fp32 [n,4,H,W].  Batch rows: [uncond x n ; cond x n] (ldm order)."""
         n = self.n
         self.unet.x[:n].copy_(x); self.unet.x[n:].copy_(x)
         self.unet.temb.copy_(temb_row.unsqueeze(0).expand(2 * n, -1))
-        self.unet.execute(self.use_hip_graph)
+        self.unet.execute(self.use_hip_graph, static_unchanged=not self._ctx_fresh)
+        self._ctx_fresh = False
         return ops.cfg_combine(self.unet.eps, guidance, uncond_first=True, mode=mode)
 
     # ------------------------------------------------------------------ samplers

