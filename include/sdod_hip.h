@@ -65,8 +65,20 @@ typedef struct sdod_gemm_desc {
     int act;
     float alpha;
     int bias_on_m;
-    int split_k;                   /* 0/1 = none; >1 = number of K slices (needs workspace) */
+    int split_k;                   /* 0 = auto; 1 = none; >1 = number of K slices (needs workspace) */
     int tile;                      /* 0 = auto; else forces a tile config (see gemm.hip) */
+    /* --- fusions (LDS-DMA kernel family only) ---
+     * geglu: W has N rows laid out as interleaved 16-row blocks [a(16) | gate(16)]...; out gets N/2 columns:
+     *        out = (acc_a + bias_a) * gelu(acc_gate + bias_gate)    (ldm GEGLU: x * gelu(gate), fused into ff.net.0.proj)
+     * tail segment: K columns [k_tail, K) of W multiply a SECOND, 1x1-gathered NHWC source (t0 | t1 channel concat) at the
+     *        output pixel: out = conv3x3(a|a2) + conv1x1(t0|t1)  (ResBlock out_layers.3 + skip_connection in one GEMM);
+     *        bias2 is added like bias. */
+    int geglu;
+    int k_tail;                    /* 0 = no tail segment; else 9*(c0+c1) */
+    const void* t0;
+    const void* t1;
+    int tc0, tc1;
+    const void* bias2;
 } sdod_gemm_desc;
 
 SDOD_API int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream);

@@ -27,6 +27,8 @@ enum ParamKind {
     PK_EMBED,       // [rows][dim] -> fp16
     PK_VEC,         // [n] -> fp32
     PK_MAT_F32,     // small matrix kept in fp32 (post_quant_conv 4x4)
+    PK_LINEAR_GEGLU, // [2H][in] -> fp16, rows interleaved in 16-row blocks [value | gate] for the fused GEGLU epilogue
+    PK_VEC_GEGLU,    // [2H] -> fp32, same interleave
 };
 
 struct Param {
@@ -34,6 +36,9 @@ struct Param {
     std::vector<int64_t> shape; // canonical (PyTorch) shape
     ParamKind kind;
     int group = -1;
+    int ld = 0;       // row stride in elements when the rows sit inside a wider matrix (0 = dense)
+    int col_off = 0;  // first column inside that matrix
+    int owner = -1;   // >= 0: this parameter aliases columns of params_[owner]'s allocation
     size_t dev_bytes = 0;
     char* dev = nullptr;
     bool set = false;
@@ -85,6 +90,8 @@ private:
     char* weight_base_ = nullptr;
     size_t weight_bytes_ = 0;
     int P(const std::string& name, std::vector<int64_t> shape, ParamKind kind, const std::string& group = "");
+    // parameter stored as a column block [col_off, col_off + K) of a wider [rows][ld] fp16 matrix (owner < 0: allocates it)
+    int Pc(const std::string& name, std::vector<int64_t> shape, ParamKind kind, int ld, int col_off, int owner);
     template <typename T>
     const T* W(int idx) const { return reinterpret_cast<const T*>(params_[idx].dev); }
     void allocate_weights();
@@ -145,6 +152,10 @@ private:
         float alpha = 1.0f;
         bool bias_on_m = false;
         int lda = 0, ldo = 0;      // 0 = dense
+        bool geglu = false;        // fused value*gelu(gate) epilogue (weights packed PK_LINEAR_GEGLU)
+        const Act* tail0 = nullptr; // conv(): 1x1-gathered tail segment sources (ResBlock skip connection)
+        const Act* tail1 = nullptr;
+        int bias2 = -1;
     };
     void emit_gemm(sdod_gemm_desc d);
     // out[rows][N] = x[rows][K] . W^T ; W is params_[w] (or a raw fp16 [N][K] pointer through *_raw)

@@ -68,8 +68,10 @@ static size_t param_dev_bytes(const Param& p) {
     case PK_CONV3_SMALL: return (size_t)s[0] * 64 * sizeof(f16);
     case PK_CONV1:
     case PK_LINEAR:
+    case PK_LINEAR_GEGLU:
     case PK_EMBED: return (size_t)s[0] * s[1] * sizeof(f16);
-    case PK_VEC: return (size_t)s[0] * sizeof(float);
+    case PK_VEC:
+    case PK_VEC_GEGLU: return (size_t)s[0] * sizeof(float);
     case PK_MAT_F32: {
         size_t n = 1;
         for (auto d : s) n *= (size_t)d;
@@ -106,6 +108,18 @@ int Graph::P(const std::string& name, std::vector<int64_t> shape, ParamKind kind
     return (int)params_.size() - 1;
 }
 
+int Graph::Pc(const std::string& name, std::vector<int64_t> shape, ParamKind kind, int ld, int col_off, int owner) {
+    const int idx = P(name, std::move(shape), kind);
+    if (mode_ == DECLARE) {
+        Param& p = params_[idx];
+        p.ld = ld;
+        p.col_off = col_off;
+        p.owner = owner;
+        p.dev_bytes = owner < 0 ? (size_t)p.shape[0] * ld * sizeof(f16) : 0;
+    }
+    return idx;
+}
+
 void Graph::allocate_weights() {
     // groups first (members contiguous, declaration order), then everything else; 256-byte alignment per block
     size_t off = 0;
@@ -128,6 +142,8 @@ void Graph::allocate_weights() {
     SDOD_HIP_CHECK(hipMalloc((void**)&weight_base_, weight_bytes_));
     SDOD_HIP_CHECK(hipMemset(weight_base_, 0, weight_bytes_));
     for (size_t i = 0; i < params_.size(); ++i) params_[i].dev = weight_base_ + offs[i];
+    for (auto& p : params_)
+        if (p.owner >= 0) p.dev = params_[p.owner].dev + (size_t)p.col_off * sizeof(f16);
 }
 
 template <typename S>
@@ -158,6 +174,27 @@ static void pack_param_host(const Param& p, const S* src, char* dst_raw) {
         parallel_for(n, [&](int64_t b, int64_t e) {
             for (int64_t i = b; i < e; ++i) dst[i] = (f16)(float)src[i];
         });
+        break;
+    }
+    case PK_LINEAR_GEGLU: { // value row j -> (j/16)*32 + j%16 ; gate row H+j -> (j/16)*32 + 16 + j%16
+        const int64_t rows = s[0], k = s[1], H = rows / 2;
+        f16* dst = reinterpret_cast<f16*>(dst_raw);
+        parallel_for(rows, [&](int64_t b, int64_t e) {
+            for (int64_t r = b; r < e; ++r) {
+                const int64_t j = r < H ? r : r - H;
+                const int64_t nr = (j / 16) * 32 + (r < H ? 0 : 16) + j % 16;
+                for (int64_t c = 0; c < k; ++c) dst[nr * k + c] = (f16)(float)src[r * k + c];
+            }
+        });
+        break;
+    }
+    case PK_VEC_GEGLU: {
+        const int64_t rows = s[0], H = rows / 2;
+        float* dst = reinterpret_cast<float*>(dst_raw);
+        for (int64_t r = 0; r < rows; ++r) {
+            const int64_t j = r < H ? r : r - H;
+            dst[(j / 16) * 32 + (r < H ? 0 : 16) + j % 16] = (float)src[r];
+        }
         break;
     }
     case PK_VEC:
@@ -191,10 +228,19 @@ void Graph::set_param(const std::string& name, const void* data, int dtype, cons
         for (int i = 0; i < ndim; ++i) m += std::to_string(shape[i]) + ",";
         throw Error(INVALID_ARGUMENT, m + "]");
     }
-    std::vector<char> staging(p.dev_bytes);
-    if (dtype == SDOD_F32) pack_param_host(p, reinterpret_cast<const float*>(data), staging.data());
-    else pack_param_host(p, reinterpret_cast<const f16*>(data), staging.data());
-    SDOD_HIP_CHECK(hipMemcpy(p.dev, staging.data(), p.dev_bytes, hipMemcpyHostToDevice));
+    Param dense = p; // packing always produces the dense image; strided parameters are placed with a 2-D copy
+    dense.ld = 0;
+    const size_t dense_bytes = param_dev_bytes(dense);
+    std::vector<char> staging(dense_bytes);
+    if (dtype == SDOD_F32) pack_param_host(dense, reinterpret_cast<const float*>(data), staging.data());
+    else pack_param_host(dense, reinterpret_cast<const f16*>(data), staging.data());
+    if (p.ld > 0) {
+        const size_t row_bytes = dense_bytes / (size_t)p.shape[0];
+        SDOD_HIP_CHECK(hipMemcpy2D(p.dev, (size_t)p.ld * sizeof(f16), staging.data(), row_bytes, row_bytes, (size_t)p.shape[0],
+                                   hipMemcpyHostToDevice));
+    } else {
+        SDOD_HIP_CHECK(hipMemcpy(p.dev, staging.data(), dense_bytes, hipMemcpyHostToDevice));
+    }
     p.set = true;
 }
 
@@ -345,7 +391,8 @@ bool autotune_enabled() {
     return !(e && e[0] == '0');
 }
 ShapeKey key_of(const sdod_gemm_desc& d) {
-    return ShapeKey{{d.a_mode, d.M, d.N, d.K, d.c0, d.c1, d.stride, d.upsample, d.ksize, d.h_in, d.residual ? 1 : 0, d.lda}};
+    return ShapeKey{{d.a_mode, d.M, d.N, d.K, d.c0, d.c1, d.stride, d.upsample, d.ksize, d.h_in,
+                     (d.residual ? 1 : 0) + (d.geglu ? 2 : 0) + 4 * d.tc0 + 16384 * d.tc1, d.lda}};
 }
 } // namespace
 
@@ -435,12 +482,17 @@ void Graph::linear_raw(const f16* x, int rows, int K, const f16* w, int ldw, int
     d.row_bias = o.row_bias; d.ld_row_bias = o.ld_row_bias; d.rows_per_img = o.rows_per_img;
     d.residual = o.residual; d.ldr = d.ldo;
     d.act = o.act; d.alpha = o.alpha;
+    if (o.geglu) {
+        d.geglu = 1;
+        if (!o.ldo) d.ldo = N / 2;
+        d.ldr = d.ldo;
+    }
     emit_gemm(d);
 }
 
 void Graph::linear(const f16* x, int rows, int K, int w, int N, f16* out, const GemmOpt& o) {
     const Param& p = params_[w];
-    const int ldw = p.kind == PK_CONV3_SMALL ? 64 : (int)(p.kind == PK_CONV3 ? p.shape[1] * 9 : p.shape[1]);
+    const int ldw = p.ld > 0 ? p.ld : p.kind == PK_CONV3_SMALL ? 64 : (int)(p.kind == PK_CONV3 ? p.shape[1] * 9 : p.shape[1]);
     linear_raw(x, rows, K, reinterpret_cast<const f16*>(p.dev), ldw, N, out, o);
 }
 
@@ -456,7 +508,14 @@ Act Graph::conv(const Act& x, const Act* x2, int w, int cout, int ksize, int str
     d.w = params_[w].dev; d.out = y.p;
     const int cin = x.c + (x2 ? x2->c : 0);
     d.M = y.rows(); d.N = cout; d.K = ksize * ksize * cin;
-    d.ldw = d.K; d.ldo = cout;
+    if (o.tail0) {
+        d.k_tail = d.K;
+        d.t0 = o.tail0->p; d.tc0 = o.tail0->c;
+        d.t1 = o.tail1 ? o.tail1->p : nullptr; d.tc1 = o.tail1 ? o.tail1->c : 0;
+        d.K += d.tc0 + d.tc1;
+        if (o.bias2 >= 0) d.bias2 = params_[o.bias2].dev;
+    }
+    d.ldw = params_[w].ld > 0 ? params_[w].ld : d.K; d.ldo = cout;
     d.a_mode = SDOD_A_CONV3X3;
     d.n_img = x.n; d.h_in = x.h; d.w_in = x.w; d.c0 = x.c; d.c1 = x2 ? x2->c : 0;
     d.stride = stride; d.upsample = ups; d.ksize = ksize;

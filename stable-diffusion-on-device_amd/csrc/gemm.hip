@@ -41,6 +41,12 @@ struct GemmP {
     int mode;
     int h_in, w_in, h_out, w_out, c0, c1, stride, ups, ksize;
     int sa0, sa1; // pixel strides (elements) of the two A sources: c0/c1 for NHWC images, lda for plain rows
+    int geglu;    // epilogue pairs 16-column blocks: out = a * gelu(gate)
+    int k_tail;   // K columns >= k_tail come from the 1x1-gathered tail sources t0|t1 (0 = none)
+    const f16* t0;
+    const f16* t1;
+    int tc0, tc1;
+    const float* bias2;
     int rows_per_img, ldrb;
     int act;
     float alpha;
@@ -395,6 +401,28 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
         const int k0 = kt * BK;
         f16* sA = smem + stage * STAGE;
         f16* sB = sA + BM * 64;
+        if (p.k_tail && k0 >= p.k_tail) {
+            // tail segment: the skip connection's 1x1 conv reads the block input at the OUTPUT pixel (centre tap)
+            const int kk = k0 - p.k_tail;
+            const bool sec = kk >= p.tc0;
+            const f16* src = sec ? p.t1 : p.t0;
+            const int sa = sec ? p.tc1 : p.tc0;
+            const int ccs = sec ? kk - p.tc0 : kk;
+            const int centre = pad * p.ksize + pad;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                const int ro = ((a_im[i] + a_py[i] + pad) * p.w_in + a_px[i] + pad) * sa + ccs + lchunk * 8;
+                const bool ok = (a_mask[i] >> centre) & 1u;
+                const f16* g = ok ? src + ro : zeros;
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sA + (i * NW + wave) * 8 * 64), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) {
+                const f16* g = b_row[i] + (b_row[i] == zeros ? 0 : k0);
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * NW + wave) * 8 * 64), 16, 0, 0);
+            }
+            return;
+        }
         const int tap = k0 / cin;
         const int cc = k0 - tap * cin;
         const int r = tap / p.ksize, sx = tap - r * p.ksize;
@@ -495,6 +523,32 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
     }
 
     f16* sC = smem;
+    if (p.geglu) {
+        // 16-column blocks alternate [value | gate]; both live in the SAME lane (acc[i][j], acc[i][j+1]), so GEGLU is a
+        // register-level product and the tile that goes to memory is half as wide
+        if constexpr (TN % 2 == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int ml = wm * WTM + i * 16 + e_m;
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const int nl = wn * WTN + j * 16 + e_n; // column of the value block in W-row space
+                    const int n = n0 + nl;
+                    f16x4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float va = acc[i][j][r] * p.alpha, vg = acc[i][j + 1][r] * p.alpha;
+                        if (p.bias != nullptr && n + 16 + r < p.N) {
+                            va += p.bias[n + r];
+                            vg += p.bias[n + 16 + r];
+                        }
+                        h[r] = (f16)(va * gelu_erf_f(vg));
+                    }
+                    *reinterpret_cast<f16x4*>(sC + ml * SC + (wn * WTN + j * 16) / 2 + e_n) = h;
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int ml = wm * WTM + i * 16 + e_m;
@@ -516,6 +570,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
                         v += p.bias[n + r];
                     }
                 }
+                if (p.bias2 != nullptr && n + r < p.N) v += p.bias2[n + r];
                 if (rbias != nullptr && n + r < p.N) v += (float)rbias[n + r];
                 v = apply_act(v, p.act);
                 h[r] = (f16)v;
@@ -523,15 +578,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
             *reinterpret_cast<f16x4*>(sC + ml * SC + nl) = h;
         }
     }
+    }
     __syncthreads();
 
-    constexpr int CPR = BN / 8;
-    const bool vec_ok = (p.N % 8 == 0) && (p.ldo % 8 == 0) && (p.residual == nullptr || p.ldr % 8 == 0);
+    const int CPR = p.geglu ? BN / 16 : BN / 8; // 16-byte chunks per output tile row
+    const int n_out = p.geglu ? p.N / 2 : p.N;
+    const int n0_out = p.geglu ? n0 / 2 : n0;
+    const bool vec_ok = (n_out % 8 == 0) && (p.ldo % 8 == 0) && (p.residual == nullptr || p.ldr % 8 == 0);
     for (int idx = tid; idx < BM * CPR; idx += NT) {
         const int row = idx / CPR;
         const int ch = idx - row * CPR;
-        const int m = m0 + row, n = n0 + ch * 8;
-        if (m >= p.M || n >= p.N) continue;
+        const int m = m0 + row, n = n0_out + ch * 8;
+        if (m >= p.M || n >= n_out) continue;
         f16x8 v = *reinterpret_cast<const f16x8*>(sC + row * SC + ch * 8);
         if (vec_ok) {
             if (p.residual != nullptr) {
@@ -542,7 +600,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
             stg8(p.out + (size_t)m * p.ldo + n, v);
         } else {
             for (int e = 0; e < 8; ++e) {
-                if (n + e < p.N) {
+                if (n + e < n_out) {
                     float f = (float)v[e];
                     if (p.residual != nullptr) f += (float)p.residual[(size_t)m * p.ldr + n + e];
                     p.out[(size_t)m * p.ldo + n + e] = (f16)f;
@@ -576,6 +634,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
             if (n + r >= p.N) break;
             float f = v[r] * p.alpha;
             if (p.bias) f += p.bias_on_m ? p.bias[m] : p.bias[n + r];
+            if (p.bias2) f += p.bias2[n + r];
             if (rbias) f += (float)rbias[n + r];
             f = apply_act(f, p.act);
             f = (float)(f16)f; // same rounding point as the un-split path
@@ -647,6 +706,8 @@ Plan make_plan(const sdod_gemm_desc* d) {
     const int KT = d->K / BK;
     auto ntiles = [&](int t) { return ((d->M + kTiles[t].bm - 1) / kTiles[t].bm) * ((d->N + kTiles[t].bn - 1) / kTiles[t].bn); };
     int tile = d->tile;
+    const bool fused = d->geglu || d->k_tail;
+    if (fused && (tile < 6 || tile > kNumTiles)) tile = 14; // fusions live in the LDS-DMA kernel family only
     if (tile <= 0 || tile > kNumTiles) {
         if (d->N <= 16) {
             tile = 4;
@@ -660,6 +721,7 @@ Plan make_plan(const sdod_gemm_desc* d) {
     }
     pl.tile = tile;
     int splits = d->split_k;
+    if (d->geglu) splits = 1; // the split-K reducer does not pair value/gate columns
     if (splits <= 0) {
         splits = 1;
         const int nt = ntiles(tile);
@@ -701,7 +763,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     SDOD_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "M, N, K must be positive");
     SDOD_REQUIRE(d->K % BK == 0, "K must be a multiple of 64 (pad the weight / use im2col for Cin<64)");
     SDOD_REQUIRE(d->ldw >= d->K && d->ldw % 8 == 0, "ldw must be >= K and a multiple of 8");
-    SDOD_REQUIRE(d->ldo >= d->N, "ldo must be >= N");
+    SDOD_REQUIRE(d->ldo >= (d->geglu ? d->N / 2 : d->N), "ldo must be >= N");
     SDOD_REQUIRE(((uintptr_t)d->a & 15) == 0 && ((uintptr_t)d->w & 15) == 0, "operands must be 16-byte aligned");
     GemmP p{};
     p.a0 = (const f16*)d->a;
@@ -719,6 +781,19 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     p.alpha = d->alpha;
     p.bias_on_m = d->bias_on_m;
     p.rows_per_img = d->rows_per_img > 0 ? d->rows_per_img : 1;
+    p.geglu = d->geglu ? 1 : 0;
+    p.k_tail = d->k_tail;
+    p.t0 = (const f16*)d->t0; p.t1 = (const f16*)d->t1; p.tc0 = d->tc0; p.tc1 = d->tc1;
+    p.bias2 = (const float*)d->bias2;
+    if (d->geglu) {
+        SDOD_REQUIRE(d->N % 32 == 0 && !d->residual && !d->row_bias && !d->bias_on_m && d->act == 0, "geglu: N % 32 == 0, no residual/row_bias/act");
+        SDOD_REQUIRE(d->ldo >= d->N / 2, "geglu: ldo must be >= N/2");
+    }
+    if (d->k_tail) {
+        SDOD_REQUIRE(d->a_mode == SDOD_A_CONV3X3 && d->stride == 1 && !d->upsample, "tail segment needs a stride-1 conv");
+        SDOD_REQUIRE(d->t0 && d->tc0 > 0 && d->tc0 % 64 == 0 && d->tc1 % 64 == 0 && (d->t1 || d->tc1 == 0), "bad tail sources");
+        SDOD_REQUIRE(d->K == d->k_tail + d->tc0 + d->tc1, "K must equal k_tail + tc0 + tc1");
+    }
     if (d->residual) SDOD_REQUIRE(d->ldr >= d->N, "ldr must be >= N");
     if (d->row_bias) SDOD_REQUIRE(d->rows_per_img > 0 && !d->bias_on_m, "row_bias needs rows_per_img");
     if (d->a_mode == SDOD_A_CONV3X3) {
@@ -727,7 +802,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         SDOD_REQUIRE(d->a2 != nullptr || d->c1 == 0, "c1 > 0 needs a2");
         const int ks = d->ksize == 1 ? 1 : 3;
         SDOD_REQUIRE(d->ksize == 0 || d->ksize == 1 || d->ksize == 3, "conv kernel size must be 1 or 3");
-        SDOD_REQUIRE(d->K == ks * ks * (d->c0 + d->c1), "conv K must equal ksize^2*(c0+c1)");
+        SDOD_REQUIRE((d->k_tail ? d->k_tail : d->K) == ks * ks * (d->c0 + d->c1), "conv K must equal ksize^2*(c0+c1)");
         p.ksize = ks;
         SDOD_REQUIRE(!(d->upsample && d->stride != 1), "upsample implies stride 1");
         p.h_in = d->h_in; p.w_in = d->w_in; p.c0 = d->c0; p.c1 = d->c1;
@@ -744,6 +819,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         p.sa0 = d->lda; p.sa1 = 0;
     }
     const Plan pl = make_plan(d);
+    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2) || pl.tile >= 6, "geglu / tail segment / bias2 need an LDS-DMA tile (6..16)");
     p.splits = pl.splits;
     p.kt_per_split = pl.kt_per_split;
     if (pl.splits > 1) {

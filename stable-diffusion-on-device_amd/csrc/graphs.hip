@@ -33,12 +33,19 @@ Act Graph::res_block(const std::string& pfx, const Act& x, const Act* x2, int co
     const int n1w = P(pfx + ".in_layers.0.weight", {cin}, PK_VEC), n1b = P(pfx + ".in_layers.0.bias", {cin}, PK_VEC);
     const int c1w = P(pfx + ".in_layers.2.weight", {cout, cin, 3, 3}, PK_CONV3), c1b = P(pfx + ".in_layers.2.bias", {cout}, PK_VEC);
     const int n2w = P(pfx + ".out_layers.0.weight", {cout}, PK_VEC), n2b = P(pfx + ".out_layers.0.bias", {cout}, PK_VEC);
-    const int c2w = P(pfx + ".out_layers.3.weight", {cout, cout, 3, 3}, PK_CONV3), c2b = P(pfx + ".out_layers.3.bias", {cout}, PK_VEC);
-    int skw = -1, skb = -1;
+    // out_layers.3 (3x3) and skip_connection (1x1) share ONE weight matrix [cout][9*cout + cin]: the skip conv is the tail
+    // K-segment of the same GEMM (one launch, no intermediate skip tensor)
+    int c2w, skw = -1, skb = -1;
     if (cin != cout) {
-        skw = P(pfx + ".skip_connection.weight", {cout, cin, 1, 1}, PK_CONV1);
+        const int ld = 9 * cout + cin;
+        c2w = Pc(pfx + ".out_layers.3.weight", {cout, cout, 3, 3}, PK_CONV3, ld, 0, -1);
+        skw = Pc(pfx + ".skip_connection.weight", {cout, cin, 1, 1}, PK_CONV1, ld, 9 * cout, c2w);
         skb = P(pfx + ".skip_connection.bias", {cout}, PK_VEC);
+    } else {
+        c2w = P(pfx + ".out_layers.3.weight", {cout, cout, 3, 3}, PK_CONV3);
     }
+    const int c2b = P(pfx + ".out_layers.3.bias", {cout}, PK_VEC);
+    (void)skw;
     const int my_off = emb_off;
     emb_off += cout;
 
@@ -52,21 +59,18 @@ Act Graph::res_block(const std::string& pfx, const Act& x, const Act* x2, int co
     release(g1);
     Act g2 = group_norm(h, nullptr, n2w, n2b, 1e-5f, true);
     release(h);
-    Act s;
     GemmOpt o2;
     o2.bias = c2b;
     if (cin != cout) {
-        GemmOpt os;
-        os.bias = skb;
-        s = conv(x, x2, skw, cout, 1, 1, false, os);
-        o2.residual = s.p;
+        o2.tail0 = &x;
+        o2.tail1 = x2;
+        o2.bias2 = skb;
     } else {
         if (x2) throw Error(INTERNAL_ERROR, "identity skip with a concatenated input");
         o2.residual = x.p;
     }
     Act out = conv(g2, nullptr, c2w, cout, 3, 1, false, o2);
     release(g2);
-    if (s.p) release(s);
     return out;
 }
 
@@ -94,7 +98,7 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     kv_off_ += 2 * C;
     const int o2w = P(tb + ".attn2.to_out.0.weight", {C, C}, PK_LINEAR), o2b = P(tb + ".attn2.to_out.0.bias", {C}, PK_VEC);
     const int l3w = P(tb + ".norm3.weight", {C}, PK_VEC), l3b = P(tb + ".norm3.bias", {C}, PK_VEC);
-    const int f1w = P(tb + ".ff.net.0.proj.weight", {8 * C, C}, PK_LINEAR), f1b = P(tb + ".ff.net.0.proj.bias", {8 * C}, PK_VEC);
+    const int f1w = P(tb + ".ff.net.0.proj.weight", {8 * C, C}, PK_LINEAR_GEGLU), f1b = P(tb + ".ff.net.0.proj.bias", {8 * C}, PK_VEC_GEGLU);
     const int f2w = P(tb + ".ff.net.2.weight", {C, 4 * C}, PK_LINEAR), f2b = P(tb + ".ff.net.2.bias", {C}, PK_VEC);
     const int pow_ = P(pfx + ".proj_out.weight", {C, C, 1, 1}, PK_CONV1), pob = P(pfx + ".proj_out.bias", {C}, PK_VEC);
     if (mode_ == DECLARE) return act(x.n, x.h, x.w, C);
@@ -129,12 +133,9 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     release(a2); release(t1);
     // GEGLU feed-forward
     Act n3 = layer_norm(t2, l3w, l3b, 1e-5f);
-    f16* ff = alloc((size_t)rows * 8 * C);
-    { GemmOpt o; o.bias = f1b; linear(n3.p, rows, C, f1w, 8 * C, ff, o); }
+    f16* gg = alloc((size_t)rows * 4 * C); // GEGLU fused into the ff.net.0.proj epilogue: the [rows][8C] tensor never exists
+    { GemmOpt o; o.bias = f1b; o.geglu = true; linear(n3.p, rows, C, f1w, 8 * C, gg, o); }
     release(n3);
-    f16* gg = alloc((size_t)rows * 4 * C);
-    emit([=](hipStream_t st) { check_rc2(sdod_geglu_f16(ff, gg, rows, 4 * C, st)); }, "geglu", 0, 3.0 * rows * 4 * C * 2);
-    release(ff);
     Act t3 = act(B, 1, L, C);
     { GemmOpt o; o.bias = f2b; o.residual = t2.p; linear(gg, rows, 4 * C, f2w, C, t3.p, o); }
     release(gg); release(t2);

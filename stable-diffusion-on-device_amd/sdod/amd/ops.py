@@ -45,7 +45,7 @@ def workspace(nbytes, device, tag='default'):
 
 
 def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=None, alpha=1.0, out=None,
-         conv=None, a2=None, bias_on_m=False, split_k=0, tile=0, time_iters=0):
+         conv=None, a2=None, bias_on_m=False, split_k=0, tile=0, time_iters=0, geglu=False, tail=None, bias2=None):
     """out = act(alpha * A @ W^T + bias + row_bias) + residual.
 
     a: fp16 [M, K] (rows mode) or NHWC [N, H, W, C0] with conv=dict(stride=1|2, upsample=bool) (3x3 pad 1);
@@ -78,14 +78,25 @@ def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=N
         d.stride, d.upsample = stride, ups
         d.a2 = _p(a2)
         out_shape = (n_img, ho, wo, nout)
+    nvis = nout // 2 if geglu else nout
+    if geglu:
+        out_shape = out_shape[:-1] + (nvis,)
     if out is None:
         out = torch.empty(out_shape, dtype=torch.float16, device=a.device)
     else:
         _req(out, torch.float16, 'out')
-        assert out.numel() == m * nout
+        assert out.numel() == m * nvis
     d.a, d.w, d.out = _p(a), _p(w), _p(out)
     d.M, d.N, d.K = m, nout, k
-    d.ldw, d.ldo = k, nout
+    d.ldw, d.ldo = k, nvis
+    d.geglu = 1 if geglu else 0
+    if tail is not None:      # (t0, t1 or None): NHWC tensors read by the 1x1 tail segment; w holds [main K | tail K] columns
+        t0, t1 = tail
+        d.t0 = _p(t0); d.tc0 = t0.shape[-1]
+        d.t1 = _p(t1); d.tc1 = t1.shape[-1] if t1 is not None else 0
+        d.k_tail = k - d.tc0 - d.tc1
+    if bias2 is not None:
+        _req(bias2, torch.float32, 'bias2'); d.bias2 = _p(bias2)
     if bias is not None:
         _req(bias, torch.float32, 'bias'); d.bias = _p(bias)
     if row_bias is not None:

@@ -149,6 +149,40 @@ def test_conv1x1_two_sources():
     check(out, ref, name='conv1x1 concat')
 
 
+@pytest.mark.parametrize('tile', [0, 6, 8, 10, 14, 16])
+def test_gemm_fused_geglu(tile):
+    """ff.net.0.proj + GEGLU in one launch: weight rows interleaved in 16-row [value | gate] blocks"""
+    from sdod.amd import ops
+    m, c = 600, 320
+    x = rnd((m, c), 90); w = rnd((8 * c, c), 91, c ** -0.5); b = torch.randn(8 * c, generator=torch.Generator().manual_seed(92))
+    y = x.float() @ w.float().t() + b
+    ref = y[:, :4 * c] * F.gelu(y[:, 4 * c:])
+    H = 4 * c
+    perm = torch.empty(2 * H, dtype=torch.long)
+    j = torch.arange(H)
+    perm[(j // 16) * 32 + j % 16] = j
+    perm[(j // 16) * 32 + 16 + j % 16] = H + j
+    d = dev()
+    out = ops.gemm(x.to(d), w[perm].contiguous().to(d), b[perm].contiguous().to(d), geglu=True, tile=tile)
+    assert out.shape == (m, H)
+    check(out, ref, name=f'fused geglu tile{tile}')
+
+
+@pytest.mark.parametrize('tile', [0, 7, 9, 12, 14])
+def test_conv3x3_with_skip_tail_segment(tile):
+    """ResBlock: out_layers.3 (3x3 on h) + skip_connection (1x1 on the concatenated block input) as ONE GEMM"""
+    from sdod.amd import ops
+    n, h, w, cmid, c0, c1 = 2, 16, 16, 128, 128, 64
+    hmid = rnd((n, h, w, cmid), 93); x0 = rnd((n, h, w, c0), 94); x1 = rnd((n, h, w, c1), 95)
+    w3 = rnd((cmid, 9 * cmid), 96, (9 * cmid) ** -0.5); w1 = rnd((cmid, c0 + c1), 97, (c0 + c1) ** -0.5)
+    b3 = torch.randn(cmid, generator=torch.Generator().manual_seed(98)); b1 = torch.randn(cmid, generator=torch.Generator().manual_seed(99))
+    ref = conv_ref(hmid, w3, b3) + (torch.cat([x0, x1], -1).float() @ w1.float().t() + b1)
+    d = dev()
+    wcat = torch.cat([w3, w1], 1).contiguous()
+    out = ops.gemm(hmid.to(d), wcat.to(d), b3.to(d), conv=dict(stride=1), tail=(x0.to(d), x1.to(d)), bias2=b1.to(d), tile=tile)
+    check(out, ref, name=f'conv + skip tail tile{tile}')
+
+
 def test_conv_small_cin_via_im2col():
     from sdod.amd import ops
     n, h, w, cin, cout = 2, 64, 64, 4, 320
