@@ -72,13 +72,20 @@ typedef struct sdod_gemm_desc {
      *        out = (acc_a + bias_a) * gelu(acc_gate + bias_gate)    (ldm GEGLU: x * gelu(gate), fused into ff.net.0.proj)
      * tail segment: K columns [k_tail, K) of W multiply a SECOND, 1x1-gathered NHWC source (t0 | t1 channel concat) at the
      *        output pixel: out = conv3x3(a|a2) + conv1x1(t0|t1)  (ResBlock out_layers.3 + skip_connection in one GEMM);
-     *        bias2 is added like bias. */
+     *        bias2 is added like bias.
+     * ln: the rows of A are LayerNorm-ed on the fly (rows mode, K = normalised width, no split-K): the kernel sums
+     *        x and x^2 of every row while the slabs pass through LDS and the epilogue applies
+     *        out = rstd_m * (acc - mean_m * ln_s[n]) + bias[n]; the LayerNorm weight is pre-multiplied into W, ln_s[n] =
+     *        sum_k W'[n][k] and bias[n] = sum_k beta[k] W[n][k] (+ linear bias) come from sdod_ln_fold_f16. */
     int geglu;
     int k_tail;                    /* 0 = no tail segment; else 9*(c0+c1) */
     const void* t0;
     const void* t1;
     int tc0, tc1;
     const void* bias2;
+    int ln;
+    const void* ln_s;              /* fp32 [N] */
+    float ln_eps;
 } sdod_gemm_desc;
 
 SDOD_API int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream);
@@ -97,6 +104,10 @@ SDOD_API int sdod_group_norm_nhwc(const void* x, const void* x2, void* y, const 
                                   int n, int hw, int c0, int c1, int groups, float eps, int silu, int dtype,
                                   void* workspace, void* stream);
 
+/* Folds a LayerNorm (gamma, beta over K) into the Linear that consumes it, in place: t_out[n] = sum_k beta[k]*W[n][k]
+ * (+ bias_in[n]); W[n][k] <- fp16(W[n][k]*gamma[k]); s_out[n] = sum_k W'[n][k].  Used once per weight at graph build. */
+SDOD_API int sdod_ln_fold_f16(void* w, int n, int k, int ldw, const float* gamma, const float* beta, const float* bias_in,
+                              float* s_out, float* t_out, void* stream);
 /* LayerNorm over the last dim of fp16 [M][C] rows, fp32 weight/bias. */
 SDOD_API int sdod_layer_norm_f16(const void* x, void* y, const float* weight, const float* bias, int m, int c,
                                  float eps, void* stream);

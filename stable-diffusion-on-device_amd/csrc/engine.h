@@ -156,7 +156,15 @@ private:
         const Act* tail0 = nullptr; // conv(): 1x1-gathered tail segment sources (ResBlock skip connection)
         const Act* tail1 = nullptr;
         int bias2 = -1;
+        int ln_w = -1, ln_b = -1;  // fold LayerNorm(ln_w, ln_b) of the input rows into this Linear (see sdod_ln_fold_f16)
     };
+    struct FoldJob {
+        f16* w; int n, k, ldw;
+        const float *gamma, *beta, *bias_in;
+        float *s, *t;
+    };
+    std::vector<FoldJob> fold_jobs_;
+    std::vector<void*> derived_; // device buffers created at build time (folded LayerNorm vectors)
     void emit_gemm(sdod_gemm_desc d);
     // out[rows][N] = x[rows][K] . W^T ; W is params_[w] (or a raw fp16 [N][K] pointer through *_raw)
     void linear(const f16* x, int rows, int K, int w, int N, f16* out, const GemmOpt& o);

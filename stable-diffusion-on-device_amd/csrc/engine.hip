@@ -58,6 +58,7 @@ Graph::~Graph() {
     (void)hipFree(ws_);
     (void)hipFree(gn_ws_);
     (void)hipFree(kv_all_);
+    for (void* d : derived_) (void)hipFree(d);
 }
 
 // ------------------------------------------------------------------------------------------ parameters
@@ -209,6 +210,7 @@ static void pack_param_host(const Param& p, const S* src, char* dst_raw) {
 }
 
 void Graph::set_param(const std::string& name, const void* data, int dtype, const int64_t* shape, int ndim) {
+    SDOD_REQUIRE(!finalized_, "parameters cannot change after finalize() (weights are repacked / folded in place)");
     auto it = pindex_.find(name);
     SDOD_REQUIRE(it != pindex_.end(), "unknown parameter '" + name + "'");
     SDOD_REQUIRE(data != nullptr, "null data for '" + name + "'");
@@ -392,7 +394,7 @@ bool autotune_enabled() {
 }
 ShapeKey key_of(const sdod_gemm_desc& d) {
     return ShapeKey{{d.a_mode, d.M, d.N, d.K, d.c0, d.c1, d.stride, d.upsample, d.ksize, d.h_in,
-                     (d.residual ? 1 : 0) + (d.geglu ? 2 : 0) + 4 * d.tc0 + 16384 * d.tc1, d.lda}};
+                     (d.residual ? 1 : 0) + (d.geglu ? 2 : 0) + 4 * d.tc0 + 16384 * d.tc1 + (d.ln ? (1 << 30) : 0), d.lda}};
 }
 } // namespace
 
@@ -486,6 +488,26 @@ void Graph::linear_raw(const f16* x, int rows, int K, const f16* w, int ldw, int
         d.geglu = 1;
         if (!o.ldo) d.ldo = N / 2;
         d.ldr = d.ldo;
+    }
+    if (o.ln_w >= 0) {
+        // LayerNorm folded into this Linear: gamma goes into W (in place, once, after all parameters are set), the
+        // kernel gathers the row statistics itself; s/t are derived vectors owned by the graph
+        d.ln = 1;
+        d.ln_eps = 1e-5f;
+        if (mode_ == REAL) {
+            float *sv = nullptr, *tv = nullptr;
+            SDOD_HIP_CHECK(hipMalloc((void**)&sv, (size_t)N * sizeof(float)));
+            SDOD_HIP_CHECK(hipMalloc((void**)&tv, (size_t)N * sizeof(float)));
+            derived_.push_back(sv);
+            derived_.push_back(tv);
+            fold_jobs_.push_back(FoldJob{const_cast<f16*>(w), N, K, ldw, W<float>(o.ln_w), W<float>(o.ln_b),
+                                         reinterpret_cast<const float*>(d.bias), sv, tv});
+            d.ln_s = sv;
+            d.bias = tv;
+        } else {
+            d.ln_s = d.w; // placeholder pointers for the sizing pass
+            d.bias = d.w;
+        }
     }
     emit_gemm(d);
 }
@@ -602,8 +624,12 @@ void Graph::finalize() {
     arena_reset();
     ops_.clear();
     static_ops_.clear();
+    fold_jobs_.clear();
     flops_ = 0;
     build();
+    for (const FoldJob& j : fold_jobs_)
+        check_rc(sdod_ln_fold_f16(j.w, j.n, j.k, j.ldw, j.gamma, j.beta, j.bias_in, j.s, j.t, nullptr));
+    SDOD_HIP_CHECK(hipDeviceSynchronize());
     finalized_ = true;
 }
 

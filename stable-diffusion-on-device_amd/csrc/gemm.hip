@@ -47,6 +47,9 @@ struct GemmP {
     const f16* t1;
     int tc0, tc1;
     const float* bias2;
+    int ln;            // LayerNorm of the A rows folded into this GEMM (row statistics gathered from the LDS slabs)
+    const float* ln_s;
+    float ln_eps;
     int rows_per_img, ldrb;
     int act;
     float alpha;
@@ -464,6 +467,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
 
     const int frag_row = lane & 15;
     const int frag_chunk = lane >> 4;
+    float rs1[A_LD], rs2[A_LD]; // LayerNorm fold: this lane's share of sum(x), sum(x^2) of the rows it DMA-ed
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) rs1[i] = rs2[i] = 0.f;
 
     // prologue: STAGES-1 slabs in flight (issue even past the end -- against the zero line -- so counts stay uniform)
 #pragma unroll
@@ -482,6 +488,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
 
         const f16* sA = smem + (it % STAGES) * STAGE;
         const f16* sB = sA + BM * 64;
+        if (p.ln) {
+            // every lane re-reads the 16 bytes it DMA-ed into this slab (lane-linear image: conflict-free) -- all of
+            // the row's K columns pass through here, so the row statistics cost one extra LDS read per slab
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(sA + (i * NW + wave) * 8 * 64 + lane * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[e];
+                    rs1[i] += f;
+                    rs2[i] += f * f;
+                }
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             f16x8 xa[TM], wb[TN];
@@ -502,6 +522,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
 
     const int e_m = lane & 15;
     const int e_n = (lane >> 4) * 4;
+    float* ln_stats = reinterpret_cast<float*>(smem_raw + (size_t)BM * SC * sizeof(f16)); // [BM][2] mean, rstd
+    if (p.ln) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            float a1 = rs1[i], a2 = rs2[i];
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                a1 += __shfl_xor(a1, o);
+                a2 += __shfl_xor(a2, o);
+            }
+            if ((lane & 7) == 0) {
+                const float mean = a1 / (float)p.K;
+                float var = a2 / (float)p.K - mean * mean;
+                var = var < 0.f ? 0.f : var;
+                const int r = (i * NW + wave) * 8 + lrow;
+                ln_stats[2 * r] = mean;
+                ln_stats[2 * r + 1] = 1.0f / sqrtf(var + p.ln_eps);
+            }
+        }
+        __syncthreads();
+    }
     if (p.splits > 1) {
         float* slab = p.partial + (size_t)split * p.M * p.N;
 #pragma unroll
@@ -538,6 +579,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float va = acc[i][j][r] * p.alpha, vg = acc[i][j + 1][r] * p.alpha;
+                        if (p.ln && n + 16 + r < p.N) {
+                            const float mean = ln_stats[2 * ml], rstd = ln_stats[2 * ml + 1];
+                            va = rstd * (va - mean * p.ln_s[n + r]);
+                            vg = rstd * (vg - mean * p.ln_s[n + 16 + r]);
+                        }
                         if (p.bias != nullptr && n + 16 + r < p.N) {
                             va += p.bias[n + r];
                             vg += p.bias[n + 16 + r];
@@ -563,6 +609,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = acc[i][j][r] * p.alpha;
+                if (p.ln && n + r < p.N) v = ln_stats[2 * ml + 1] * (v - ln_stats[2 * ml] * p.ln_s[n + r]);
                 if (p.bias != nullptr) {
                     if (p.bias_on_m) {
                         if (m < p.M) v += p.bias[m];
@@ -666,7 +713,7 @@ const f16* zero_line() {
 template <int BM, int BN, int WM, int WN, int STAGES>
 hipError_t launch_glds(const GemmP& p, dim3 grid, hipStream_t st) {
     constexpr size_t ring = (size_t)STAGES * (BM + BN) * 64 * sizeof(f16);
-    constexpr size_t ctile = (size_t)BM * (BN + 8) * sizeof(f16);
+    constexpr size_t ctile = (size_t)BM * (BN + 8) * sizeof(f16) + (size_t)BM * 2 * sizeof(float); // + LayerNorm row stats
     constexpr size_t smem = ring > ctile ? ring : ctile;
     static bool attr_set = false;
     if (!attr_set) {
@@ -706,7 +753,7 @@ Plan make_plan(const sdod_gemm_desc* d) {
     const int KT = d->K / BK;
     auto ntiles = [&](int t) { return ((d->M + kTiles[t].bm - 1) / kTiles[t].bm) * ((d->N + kTiles[t].bn - 1) / kTiles[t].bn); };
     int tile = d->tile;
-    const bool fused = d->geglu || d->k_tail;
+    const bool fused = d->geglu || d->k_tail || d->ln;
     if (fused && (tile < 6 || tile > kNumTiles)) tile = 14; // fusions live in the LDS-DMA kernel family only
     if (tile <= 0 || tile > kNumTiles) {
         if (d->N <= 16) {
@@ -721,7 +768,7 @@ Plan make_plan(const sdod_gemm_desc* d) {
     }
     pl.tile = tile;
     int splits = d->split_k;
-    if (d->geglu) splits = 1; // the split-K reducer does not pair value/gate columns
+    if (d->geglu || d->ln) splits = 1; // the split-K reducer neither pairs value/gate columns nor sees whole rows
     if (splits <= 0) {
         splits = 1;
         const int nt = ntiles(tile);
@@ -785,6 +832,10 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     p.k_tail = d->k_tail;
     p.t0 = (const f16*)d->t0; p.t1 = (const f16*)d->t1; p.tc0 = d->tc0; p.tc1 = d->tc1;
     p.bias2 = (const float*)d->bias2;
+    p.ln = d->ln ? 1 : 0;
+    p.ln_s = (const float*)d->ln_s;
+    p.ln_eps = d->ln_eps;
+    if (d->ln) SDOD_REQUIRE(d->a_mode == SDOD_A_ROWS && d->ln_s != nullptr && !d->bias_on_m, "ln fold needs rows mode and ln_s");
     if (d->geglu) {
         SDOD_REQUIRE(d->N % 32 == 0 && !d->residual && !d->row_bias && !d->bias_on_m && d->act == 0, "geglu: N % 32 == 0, no residual/row_bias/act");
         SDOD_REQUIRE(d->ldo >= d->N / 2, "geglu: ldo must be >= N/2");
@@ -819,7 +870,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         p.sa0 = d->lda; p.sa1 = 0;
     }
     const Plan pl = make_plan(d);
-    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2) || pl.tile >= 6, "geglu / tail segment / bias2 need an LDS-DMA tile (6..16)");
+    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln) || pl.tile >= 6, "geglu / tail segment / bias2 / ln need an LDS-DMA tile (6..16)");
     p.splits = pl.splits;
     p.kt_per_split = pl.kt_per_split;
     if (pl.splits > 1) {

@@ -108,10 +108,10 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     { GemmOpt o; o.bias = pib; linear(g.p, rows, C, piw, C, t0.p, o); }
     release(g);
     // self-attention
-    Act n1 = layer_norm(t0, l1w, l1b, 1e-5f);
+    // the three LayerNorms of the block are folded into the Linear that consumes them (no LN launch, no LN tensor)
     f16* qkv = alloc((size_t)rows * 3 * C);
-    linear_raw(n1.p, rows, C, reinterpret_cast<const f16*>(group_base(gq)), C, 3 * C, qkv, GemmOpt{});
-    release(n1);
+    { GemmOpt o; o.ln_w = l1w; o.ln_b = l1b;
+      linear_raw(t0.p, rows, C, reinterpret_cast<const f16*>(group_base(gq)), C, 3 * C, qkv, o); }
     f16* a1 = alloc((size_t)rows * C);
     attention(qkv, qkv + C, qkv + 2 * C, a1, B, heads, L, L, d, 3 * C, 3 * C, 3 * C, C, false);
     release(qkv);
@@ -119,10 +119,8 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     { GemmOpt o; o.bias = o1b; o.residual = t0.p; linear(a1, rows, C, o1w, C, t1.p, o); }
     release(a1); release(t0);
     // cross-attention on the text context
-    Act n2 = layer_norm(t1, l2w, l2b, 1e-5f);
     f16* q2 = alloc((size_t)rows * C);
-    linear(n2.p, rows, C, q2w, C, q2, GemmOpt{});
-    release(n2);
+    { GemmOpt o; o.ln_w = l2w; o.ln_b = l2b; linear(t1.p, rows, C, q2w, C, q2, o); }
     const int Lk = ctx.w;
     const f16* kv = kv_all_ + my_kv;
     f16* a2 = alloc((size_t)rows * C);
@@ -132,10 +130,8 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     { GemmOpt o; o.bias = o2b; o.residual = t1.p; linear(a2, rows, C, o2w, C, t2.p, o); }
     release(a2); release(t1);
     // GEGLU feed-forward
-    Act n3 = layer_norm(t2, l3w, l3b, 1e-5f);
     f16* gg = alloc((size_t)rows * 4 * C); // GEGLU fused into the ff.net.0.proj epilogue: the [rows][8C] tensor never exists
-    { GemmOpt o; o.bias = f1b; o.geglu = true; linear(n3.p, rows, C, f1w, 8 * C, gg, o); }
-    release(n3);
+    { GemmOpt o; o.bias = f1b; o.geglu = true; o.ln_w = l3w; o.ln_b = l3b; linear(t2.p, rows, C, f1w, 8 * C, gg, o); }
     Act t3 = act(B, 1, L, C);
     { GemmOpt o; o.bias = f2b; o.residual = t2.p; linear(gg, rows, 4 * C, f2w, C, t3.p, o); }
     release(gg); release(t2);

@@ -395,7 +395,47 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const f16* x, f16* y, c
     }
 }
 
+// LayerNorm -> Linear folding (one workgroup per weight row)
+__global__ __launch_bounds__(256) void ln_fold_kernel(f16* w, int N, int K, int ldw, const float* gamma, const float* beta,
+                                                      const float* bias_in, float* s_out, float* t_out) {
+    __shared__ float red[8];
+    const int n = blockIdx.x;
+    f16* row = w + (size_t)n * ldw;
+    float t = 0.f, sacc = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float wv = (float)row[k];
+        t += beta[k] * wv;
+        const f16 folded = (f16)(wv * gamma[k]);
+        row[k] = folded;
+        sacc += (float)folded;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        t += __shfl_xor(t, o);
+        sacc += __shfl_xor(sacc, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = t;
+        red[4 + (threadIdx.x >> 6)] = sacc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        t_out[n] = red[0] + red[1] + red[2] + red[3] + (bias_in ? bias_in[n] : 0.f);
+        s_out[n] = red[4] + red[5] + red[6] + red[7];
+    }
+}
+
 } // namespace
+
+extern "C" int sdod_ln_fold_f16(void* w, int n, int k, int ldw, const float* gamma, const float* beta, const float* bias_in,
+                                float* s_out, float* t_out, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(w && gamma && beta && s_out && t_out && n > 0 && k > 0 && ldw >= k, "bad argument");
+    hipLaunchKernelGGL(ln_fold_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (f16*)w, n, k, ldw, gamma, beta, bias_in, s_out, t_out);
+    SDOD_HIP_CHECK(hipGetLastError());
+    return 0;
+    SDOD_CATCH
+}
 
 extern "C" size_t sdod_group_norm_workspace_bytes(int n, int groups) {
     if (n <= 0 || groups <= 0) return 0;

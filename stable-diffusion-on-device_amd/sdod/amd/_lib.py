@@ -52,7 +52,7 @@ class GemmDesc(ctypes.Structure):
         ('stride', c_int), ('upsample', c_int), ('ksize', c_int), ('rows_per_img', c_int), ('ld_row_bias', c_int),
         ('act', c_int), ('alpha', c_float), ('bias_on_m', c_int), ('split_k', c_int), ('tile', c_int),
         ('geglu', c_int), ('k_tail', c_int), ('t0', c_void_p), ('t1', c_void_p), ('tc0', c_int), ('tc1', c_int),
-        ('bias2', c_void_p),
+        ('bias2', c_void_p), ('ln', c_int), ('ln_s', c_void_p), ('ln_eps', c_float),
     ]
 
 
@@ -66,6 +66,7 @@ def _declare(lib):
         'sdod_group_norm_workspace_bytes': (c_size_t, [c_int, c_int]),
         'sdod_group_norm_nhwc': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, P, P]),
         'sdod_layer_norm_f16': (c_int, [P, P, P, P, c_int, c_int, c_float, P]),
+        'sdod_ln_fold_f16': (c_int, [P, c_int, c_int, c_int, P, P, P, P, P, P]),
         'sdod_attention_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
         'sdod_softmax_rows_f16': (c_int, [P, P, c_int, c_int, P]),
         'sdod_geglu_f16': (c_int, [P, P, c_int, c_int, P]),
@@ -94,7 +95,7 @@ def _declare(lib):
 
 HIP_SYMBOLS = [
     'sdod_gemm_f16', 'sdod_gemm_workspace_bytes', 'sdod_gemm_plan', 'sdod_gemm_time', 'sdod_group_norm_workspace_bytes', 'sdod_group_norm_nhwc',
-    'sdod_layer_norm_f16', 'sdod_attention_f16', 'sdod_softmax_rows_f16', 'sdod_geglu_f16', 'sdod_act_f16',
+    'sdod_layer_norm_f16', 'sdod_ln_fold_f16', 'sdod_attention_f16', 'sdod_softmax_rows_f16', 'sdod_geglu_f16', 'sdod_act_f16',
     'sdod_add_f16', 'sdod_concat_channels_f16', 'sdod_im2col3x3_small_f16', 'sdod_nchw_f32_to_nhwc_f16',
     'sdod_nhwc_f16_to_nchw_f32', 'sdod_latent_prep_f16', 'sdod_embedding_f16', 'sdod_timestep_features_f16', 'sdod_cfg_combine',
     'sdod_dpm_update', 'sdod_ddim_step_f32', 'sdod_lincomb4_f32', 'sdod_image_to_u8', 'sdod_hip_last_error',

@@ -45,7 +45,8 @@ def workspace(nbytes, device, tag='default'):
 
 
 def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=None, alpha=1.0, out=None,
-         conv=None, a2=None, bias_on_m=False, split_k=0, tile=0, time_iters=0, geglu=False, tail=None, bias2=None):
+         conv=None, a2=None, bias_on_m=False, split_k=0, tile=0, time_iters=0, geglu=False, tail=None, bias2=None,
+         ln_s=None, ln_eps=1e-5):
     """out = act(alpha * A @ W^T + bias + row_bias) + residual.
 
     a: fp16 [M, K] (rows mode) or NHWC [N, H, W, C0] with conv=dict(stride=1|2, upsample=bool) (3x3 pad 1);
@@ -97,6 +98,8 @@ def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=N
         d.k_tail = k - d.tc0 - d.tc1
     if bias2 is not None:
         _req(bias2, torch.float32, 'bias2'); d.bias2 = _p(bias2)
+    if ln_s is not None:      # LayerNorm folded into this Linear: w / bias / ln_s come from ln_fold()
+        _req(ln_s, torch.float32, 'ln_s'); d.ln = 1; d.ln_s = _p(ln_s); d.ln_eps = ln_eps
     if bias is not None:
         _req(bias, torch.float32, 'bias'); d.bias = _p(bias)
     if row_bias is not None:
@@ -151,6 +154,16 @@ def group_norm_nchw(x, groups, weight=None, bias=None, eps=1e-5, silu=False):
     xl = x.detach().reshape(n, c, -1).permute(0, 2, 1).contiguous()  # [N, S, C]
     y = group_norm_nhwc(xl, groups, weight, bias, eps, silu)
     return y.permute(0, 2, 1).reshape(x.shape)
+
+
+def ln_fold(w, gamma, beta, bias=None):
+    """fold LayerNorm(gamma, beta) into Linear(w, bias): returns (w_folded fp16, s fp32, t fp32); w is modified in place"""
+    lib = _lib.hip()
+    _req(w, torch.float16, 'w'); _req(gamma, torch.float32, 'gamma'); _req(beta, torch.float32, 'beta')
+    n, k = w.shape
+    s = torch.empty(n, dtype=torch.float32, device=w.device); t = torch.empty_like(s)
+    check(lib.sdod_ln_fold_f16(_p(w), n, k, k, _p(gamma), _p(beta), _p(bias), _p(s), _p(t), _stream()))
+    return w, s, t
 
 
 def layer_norm(x, weight, bias, eps=1e-5, out=None):

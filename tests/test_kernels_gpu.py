@@ -168,6 +168,40 @@ def test_gemm_fused_geglu(tile):
     check(out, ref, name=f'fused geglu tile{tile}')
 
 
+@pytest.mark.parametrize('tile', [0, 6, 8, 11, 14])
+@pytest.mark.parametrize('m,c,n', [(600, 320, 960), (8192, 320, 320), (200, 1280, 1280)])
+def test_gemm_with_folded_layer_norm(tile, m, c, n):
+    """LayerNorm -> Linear in one launch: row statistics gathered inside the GEMM, gamma folded into W"""
+    from sdod.amd import ops
+    g = torch.Generator().manual_seed(100)
+    x = (torch.randn(m, c, generator=g) * 2 + torch.randn(m, 1, generator=g) * 3).half()     # per-row offsets
+    w = rnd((n, c), 101, c ** -0.5)
+    gamma = 1 + 0.2 * torch.randn(c, generator=g); beta = 0.3 * torch.randn(c, generator=g); bias = torch.randn(n, generator=g)
+    ref = F.layer_norm(x.float(), (c,), gamma, beta, 1e-5) @ w.float().t() + bias
+    d = dev()
+    wf, s, t = ops.ln_fold(w.clone().to(d), gamma.to(d), beta.to(d), bias.to(d))
+    out = ops.gemm(x.to(d), wf, t, ln_s=s, tile=tile)
+    check(out, ref, tol=3e-3, name=f'ln-folded gemm {m}x{c}->{n} tile{tile}')
+
+
+def test_gemm_ln_fold_with_geglu():
+    from sdod.amd import ops
+    g = torch.Generator().manual_seed(102)
+    m, c = 500, 320
+    H = 4 * c
+    x = (torch.randn(m, c, generator=g) + 1.5).half()
+    w = rnd((2 * H, c), 103, c ** -0.5); b = torch.randn(2 * H, generator=g)
+    gamma = 1 + 0.2 * torch.randn(c, generator=g); beta = 0.3 * torch.randn(c, generator=g)
+    y = F.layer_norm(x.float(), (c,), gamma, beta, 1e-5) @ w.float().t() + b
+    ref = y[:, :H] * F.gelu(y[:, H:])
+    perm = torch.empty(2 * H, dtype=torch.long); j = torch.arange(H)
+    perm[(j // 16) * 32 + j % 16] = j; perm[(j // 16) * 32 + 16 + j % 16] = H + j
+    d = dev()
+    wf, s, t = ops.ln_fold(w[perm].contiguous().to(d), gamma.to(d), beta.to(d), b[perm].contiguous().to(d))
+    out = ops.gemm(x.to(d), wf, t, ln_s=s, geglu=True)
+    check(out, ref, tol=3e-3, name='ln-fold + geglu')
+
+
 @pytest.mark.parametrize('tile', [0, 7, 9, 12, 14])
 def test_conv3x3_with_skip_tail_segment(tile):
     """ResBlock: out_layers.3 (3x3 on h) + skip_connection (1x1 on the concatenated block input) as ONE GEMM"""
