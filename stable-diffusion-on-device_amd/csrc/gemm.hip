@@ -484,38 +484,45 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
         else if (younger == 1 && STAGES > 3) wait_vmcnt<LOADS>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier(); // everyone's slab `it` is in LDS; everyone is done reading slab it-1
-        if (it + STAGES - 1 < nkt) issue_tile(kt_begin + it + STAGES - 1, (it + STAGES - 1) % STAGES);
 
+        // fragment reads for the whole slab first, then the DMA issue for slab it+STAGES-1 (its address arithmetic and
+        // VMEM issue run under the LDS latency), then one uninterrupted MFMA cluster
         const f16* sA = smem + (it % STAGES) * STAGE;
         const f16* sB = sA + BM * 64;
+        f16x8 xa[2][TM], wb[2][TN];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                xa[ks][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WTM + i * 16 + frag_row, ks * 4 + frag_chunk));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                wb[ks][j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
+        }
         if (p.ln) {
             // every lane re-reads the 16 bytes it DMA-ed into this slab (lane-linear image: conflict-free) -- all of
             // the row's K columns pass through here, so the row statistics cost one extra LDS read per slab
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) {
                 const f16x8 v = *reinterpret_cast<const f16x8*>(sA + (i * NW + wave) * 8 * 64 + lane * 8);
+                const f16x2 one2 = {(f16)1.0f, (f16)1.0f};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float f = (float)v[e];
-                    rs1[i] += f;
-                    rs2[i] += f * f;
+                for (int e = 0; e < 8; e += 2) { // v_dot2_f32_f16: two products + fp32 accumulate per instruction
+                    const f16x2 pr = {v[e], v[e + 1]};
+                    rs1[i] = __builtin_amdgcn_fdot2(pr, one2, rs1[i], false);
+                    rs2[i] = __builtin_amdgcn_fdot2(pr, pr, rs2[i], false);
                 }
             }
         }
+        if (it + STAGES - 1 < nkt) issue_tile(kt_begin + it + STAGES - 1, (it + STAGES - 1) % STAGES);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f16x8 xa[TM], wb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                xa[i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WTM + i * 16 + frag_row, ks * 4 + frag_chunk));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                wb[j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(wb[j], xa[i], acc[i][j]);
-        }
+                for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(wb[ks][j], xa[ks][i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
     }
     wait_vmcnt<0>();
     __syncthreads(); // all fragment reads done before the epilogue tile overwrites the ring

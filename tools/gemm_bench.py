@@ -30,6 +30,11 @@ SHAPES = [
     ('ff2 1280 @16', 'rows', (512, 1280, 5120)),
     ('kv ctx 1280', 'rows', (154, 2560, 768)),
     ('emb proj', 'rows', (2, 20160, 1280)),
+    ('tiny 64x64x64', 'rows', (64, 64, 64)),
+    ('tiny 64x64x640', 'rows', (64, 64, 640)),
+    ('small M2048 N640 K640', 'rows', (2048, 640, 640)),
+    ('small M512 N1280 K1280', 'rows', (512, 1280, 1280)),
+    ('small M8192 N320 K320', 'rows', (8192, 320, 320)),
     ('vae conv 128->128 @512', 'conv', (1, 512, 512, 128, 128, 1, False)),
     ('vae conv 256->256 @256', 'conv', (1, 256, 256, 256, 256, 1, False)),
     ('vae conv 512->512 @128', 'conv', (1, 128, 128, 512, 512, 1, False)),
