@@ -70,13 +70,21 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # functional rehearsal of the N>1 path on a one-GPU box: SDOD_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0 and
+    # SDOD_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); never used for reported numbers
+    share = os.environ.get('SDOD_BENCH_SHARE_DEVICE') == '1'
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        backend = os.environ.get('SDOD_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from sdod.amd import engine as E, ops, weights as Wt
     from sdod.amd.pipeline import Txt2Img, broadcast_conditioning, initial_latent
@@ -90,7 +98,7 @@ def main():
               'vae': E.VaeDecoder(cfg, 1).param_table(), 'text': E.TextEncoder(cfg, 1).param_table()}
     sds = {k: Wt.synthetic_state_dict(t, seed=1234 + i) for i, (k, t) in enumerate(tables.items())}
     log('uploading weights / building graphs')
-    pipe = Txt2Img(state_dicts=sds, images_per_gpu=n, latent_hw=64, device=f'cuda:{local_rank}',
+    pipe = Txt2Img(state_dicts=sds, images_per_gpu=n, latent_hw=64, device=f'cuda:{dev_index}',
                    use_hip_graph=not args.no_hip_graph)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     if not want_cpu:

@@ -19,6 +19,8 @@
 #include "sdod_hip.h"
 #include "host_util.h"
 
+#include <algorithm>
+
 namespace {
 
 template <typename T>
@@ -131,6 +133,30 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnP p) {
         float* dst = p.partial + (((size_t)n * p.nchunks + chunk_id) * p.G + g) * 2;
         dst[0] = a;
         dst[1] = b;
+    }
+}
+
+// Large maps (VAE 256^2 / 512^2 levels) need hundreds of statistics workgroups to stream at HBM rate; their partials are
+// collapsed to one entry per (n, group) by this small kernel so that the apply pass keeps reading a short list.
+__global__ __launch_bounds__(256) void gn_collapse_kernel(const float* partial, float* collapsed, int nchunks, int G) {
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= G) return;
+    float a = 0.f, b = 0.f;
+    for (int ch = lane; ch < nchunks; ch += 64) {
+        const float* src = partial + (((size_t)n * nchunks + ch) * G + g) * 2;
+        a += src[0];
+        b += src[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+    }
+    if (lane == 0) {
+        collapsed[((size_t)n * G + g) * 2 + 0] = a;
+        collapsed[((size_t)n * G + g) * 2 + 1] = b;
     }
 }
 
@@ -314,6 +340,8 @@ bool gn_try_small(GnP& p, hipStream_t st) {
     return true;
 }
 
+constexpr int GN_INLINE_CHUNKS = 64; // up to here the apply pass reduces the partials itself (two launches per GroupNorm)
+
 template <typename T>
 void gn_launch(GnP& p, hipStream_t st) {
     if (gn_try_small<T>(p, st)) return;
@@ -331,6 +359,12 @@ void gn_launch(GnP& p, hipStream_t st) {
     else
         hipLaunchKernelGGL((gn_stats_kernel<T, 2>), sgrid, sblock, smem_stats, st, p);
     SDOD_HIP_CHECK(hipGetLastError());
+    if (p.nchunks > GN_INLINE_CHUNKS) {
+        hipLaunchKernelGGL(gn_collapse_kernel, dim3((p.G + 3) / 4, p.N), dim3(256), 0, st, p.partial, p.stats, p.nchunks, p.G);
+        SDOD_HIP_CHECK(hipGetLastError());
+        p.partial = p.stats; // [N][1][G][2]
+        p.nchunks = 1;
+    }
     const size_t total = (size_t)p.HW * cp;
     int bx = (int)((total + 255) / 256);
     const int cap = 1024 / (p.N > 0 ? p.N : 1) + 1;
@@ -339,7 +373,7 @@ void gn_launch(GnP& p, hipStream_t st) {
     SDOD_HIP_CHECK(hipGetLastError());
 }
 
-constexpr int GN_MAX_CHUNKS = 64;
+constexpr int GN_MAX_CHUNKS = 1024;
 
 // ---------------------------------------------------------------- LayerNorm: one wave per row
 __global__ __launch_bounds__(256) void layer_norm_kernel(const f16* x, f16* y, const float* w, const float* b, int M,
@@ -458,8 +492,12 @@ extern "C" int sdod_group_norm_nhwc(const void* x, const void* x2, void* y, cons
     p.x0 = x; p.x1 = x2; p.y = y; p.w = weight; p.b = bias;
     p.N = n; p.HW = hw; p.C0 = c0; p.C1 = c1; p.C = c; p.G = groups; p.Cg = c / groups;
     p.eps = eps; p.silu = silu;
-    // enough statistics workgroups to cover the chip, bounded scratch
+    // enough statistics workgroups to cover the chip: ~512 in total, more (>= 32 KB of input each) for the VAE's big maps
     int nchunks = (512 + n - 1) / n;
+    const size_t bytes_per_img = (size_t)hw * c * (dtype == SDOD_F16 ? 2 : 4);
+    const int by_size = (int)std::min<size_t>(GN_MAX_CHUNKS, bytes_per_img / (64 * 1024));
+    if (nchunks > GN_INLINE_CHUNKS) nchunks = GN_INLINE_CHUNKS;
+    if (by_size > nchunks && n * nchunks < 512) nchunks = std::min(by_size, (1024 + n - 1) / n);
     if (nchunks > GN_MAX_CHUNKS) nchunks = GN_MAX_CHUNKS;
     if (nchunks > hw) nchunks = hw;
     p.pix_per_chunk = (hw + nchunks - 1) / nchunks;
