@@ -53,6 +53,19 @@ def host_threads():
     return max(1, min(16, n))
 
 
+# launch-list label -> kernel symbol as rocprofv3 prints it (tile table in csrc/gemm.hip)
+KERNEL_SYMBOLS = {
+    'gemm_t1': 'gemm_kernel<128, 128, 2, 2>', 'gemm_t2': 'gemm_kernel<128, 64, 2, 2>', 'gemm_t3': 'gemm_kernel<64, 64, 2, 2>',
+    'gemm_t4': 'gemm_kernel<256, 16, 4, 1>', 'gemm_t5': 'gemm_kernel<64, 128, 2, 2>',
+    'gemm_t6': 'gemm_glds_kernel<128, 128, 2, 2, 3>', 'gemm_t7': 'gemm_glds_kernel<128, 64, 2, 2, 4>',
+    'gemm_t8': 'gemm_glds_kernel<64, 64, 2, 2, 4>', 'gemm_t9': 'gemm_glds_kernel<128, 128, 2, 4, 3>',
+    'gemm_t10': 'gemm_glds_kernel<256, 128, 4, 2, 2>', 'gemm_t11': 'gemm_glds_kernel<128, 64, 4, 2, 4>',
+    'gemm_t12': 'gemm_glds_kernel<256, 64, 4, 2, 3>', 'gemm_t14': 'gemm_glds_kernel<128, 128, 2, 4, 2>',
+    'gemm_t16': 'gemm_glds_kernel<256, 256, 2, 4, 2>', 'attn_d40': 'attn_kernel<40, 2, true>',
+    'attn_d80': 'attn_kernel<80, 1, true>', 'attn_d160': 'attn_kernel<160, 1, true>',
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -176,7 +189,16 @@ def main():
         else:
             ach = d['bytes'] / (d['ms'] * 1e-3) / 1e9
             roof = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
-        roof.update(kernel=dom, launches_per_unet_eval=d['launches'], avg_launch_us=round(1e3 * d['ms'] / d['launches'], 2),
+        # HBM bytes per launch of that kernel family from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected offline in
+        # separate passes with tools/pmc_traffic.py and committed under profiles/; null when no measurement matches)
+        try:
+            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))['labels']
+            roof['traffic'] = round(tr[dom.replace('_splitk', '')]['hbm_bytes_per_launch'])
+        except (OSError, ValueError, KeyError):
+            pass
+        roof.update(kernel=dom, kernel_symbol=KERNEL_SYMBOLS.get(dom.replace('_splitk', ''), dom),
+                    flops_per_launch=round(d['flops'] / d['launches']), algorithmic_bytes_per_launch=round(d['bytes'] / d['launches']),
+                    launches_per_unet_eval=d['launches'], avg_launch_us=round(1e3 * d['ms'] / d['launches'], 2),
                     share_of_unet_eval=round(d['ms'] / total_ms, 3), unet_eval_eager_ms=round(total_ms, 3),
                     unet_eval_tflops=round(pipe.unet.stats()['flops'] / (unet_step_ms * 1e-3) / 1e12, 1),
                     families={k: dict(ms=round(v['ms'], 3), launches=v['launches'],
