@@ -25,6 +25,8 @@
 #include "sdod_hip.h"
 #include "host_util.h"
 
+#include <cstdlib>
+
 namespace {
 
 struct GemmP {
@@ -47,6 +49,8 @@ struct GemmP {
     const f16* t1;
     int tc0, tc1;
     const float* bias2;
+    unsigned mg_hw, sh_hw, mg_w, sh_w, mg_tn, sh_tn, mg_cin, sh_cin; // magic multipliers: m/(h_out*w_out), rem/w_out, lid/tiles_n, k0/cin
+    int dbg;           // developer ablation switches (SDOD_GEMM_DEBUG): 1 = skip MFMAs, 2 = skip DMA after the prologue, 4 = skip fragment reads
     int ln;            // LayerNorm of the A rows folded into this GEMM (row statistics gathered from the LDS slabs)
     const float* ln_s;
     float ln_eps;
@@ -59,6 +63,18 @@ struct GemmP {
 };
 
 constexpr int BK = 64;
+
+// n / d for n < 2^31 through a host-computed magic multiplier (the kernels' prologues are on the critical path of
+// every launch: a hardware-less integer division costs ~35 instructions)
+SDOD_DEVICE int fast_div(int n, unsigned magic, unsigned shift) {
+    return (int)(((unsigned)__umulhi((unsigned)n, magic) + (unsigned)n) >> shift);
+}
+inline void make_magic(unsigned d, unsigned* magic, unsigned* shift) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    *shift = s;
+    *magic = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+}
 
 SDOD_DEVICE int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ (row & 7)) << 3); }
 
@@ -343,7 +359,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int lid = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = lid / p.tiles_n;
+    const int tile_m = fast_div(lid, p.mg_tn, p.sh_tn);
     const int tile_n = lid - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int split = blockIdx.z;
@@ -375,20 +391,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
         const bool row_ok = m < p.M;
         const int hw = p.h_out * p.w_out;
         const int mm = row_ok ? m : 0;
-        const int img = mm / hw;
+        const int img = fast_div(mm, p.mg_hw, p.sh_hw);
         const int rem = mm - img * hw;
-        const int oy = rem / p.w_out;
+        const int oy = fast_div(rem, p.mg_w, p.sh_w);
         const int py = oy * p.stride - pad, px = (rem - oy * p.w_out) * p.stride - pad;
         a_py[i] = py; a_px[i] = px; a_im[i] = img * p.h_in;
         const int pix = (img * p.h_in + py) * p.w_in + px;
         a_ro0[i] = pix * p.sa0 + lchunk * 8;
         a_ro1[i] = pix * p.sa1 + lchunk * 8;
         unsigned mask = 0;
-        for (int t = 0; t < p.ksize * p.ksize; ++t) {
-            const int r = t / p.ksize, sx = t - r * p.ksize;
-            const bool ok = row_ok & ((unsigned)(py + r) < (unsigned)hup) & ((unsigned)(px + sx) < (unsigned)wup);
-            mask |= (ok ? 1u : 0u) << t;
-        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) {
+                const bool ok = row_ok & (r < p.ksize) & (sx < p.ksize) & ((unsigned)(py + r) < (unsigned)hup) &
+                                ((unsigned)(px + sx) < (unsigned)wup);
+                mask |= (ok ? 1u : 0u) << (r * p.ksize + sx);
+            }
         a_mask[i] = mask;
     }
     const f16* b_row[B_LD];
@@ -426,9 +445,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
             }
             return;
         }
-        const int tap = k0 / cin;
+        const int tap = fast_div(k0, p.mg_cin, p.sh_cin); // wave-uniform scalar arithmetic
         const int cc = k0 - tap * cin;
-        const int r = tap / p.ksize, sx = tap - r * p.ksize;
+        const int r = p.ksize == 3 ? tap / 3 : 0, sx = tap - r * p.ksize;
         const bool second = cc >= p.c0;
         const f16* src = second ? p.a1 : p.a0;
         const int sa = second ? p.sa1 : p.sa0;
@@ -490,6 +509,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
         const f16* sA = smem + (it % STAGES) * STAGE;
         const f16* sB = sA + BM * 64;
         f16x8 xa[2][TM], wb[2][TN];
+        if (!(p.dbg & 4)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -498,6 +518,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 wb[ks][j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
+        }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) xa[ks][i] = zero8();
+#pragma unroll
+                for (int j = 0; j < TN; ++j) wb[ks][j] = zero8();
+            }
         }
         if (p.ln) {
             // every lane re-reads the 16 bytes it DMA-ed into this slab (lane-linear image: conflict-free) -- all of
@@ -514,15 +543,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
                 }
             }
         }
-        if (it + STAGES - 1 < nkt) issue_tile(kt_begin + it + STAGES - 1, (it + STAGES - 1) % STAGES);
-        __builtin_amdgcn_s_setprio(1);
+        if (it + STAGES - 1 < nkt && !(p.dbg & 2)) issue_tile(kt_begin + it + STAGES - 1, (it + STAGES - 1) % STAGES);
+        if (!(p.dbg & 1)) {
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(wb[ks][j], xa[ks][i], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
+                    for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(wb[ks][j], xa[ks][i], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            // keep the fragment reads alive without the matrix pipe
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(wb[ks][j]));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(xa[ks][i]));
+            }
+        }
     }
     wait_vmcnt<0>();
     __syncthreads(); // all fragment reads done before the epilogue tile overwrites the ring
@@ -839,6 +879,10 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     p.k_tail = d->k_tail;
     p.t0 = (const f16*)d->t0; p.t1 = (const f16*)d->t1; p.tc0 = d->tc0; p.tc1 = d->tc1;
     p.bias2 = (const float*)d->bias2;
+    {
+        const char* e = std::getenv("SDOD_GEMM_DEBUG");
+        p.dbg = e ? std::atoi(e) : 0;
+    }
     p.ln = d->ln ? 1 : 0;
     p.ln_s = (const float*)d->ln_s;
     p.ln_eps = d->ln_eps;
@@ -888,6 +932,10 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     const TileCfg tc = kTiles[pl.tile];
     p.tiles_m = (d->M + tc.bm - 1) / tc.bm;
     p.tiles_n = (d->N + tc.bn - 1) / tc.bn;
+    make_magic((unsigned)(p.h_out * p.w_out), &p.mg_hw, &p.sh_hw);
+    make_magic((unsigned)p.w_out, &p.mg_w, &p.sh_w);
+    make_magic((unsigned)p.tiles_n, &p.mg_tn, &p.sh_tn);
+    make_magic((unsigned)(p.c0 + p.c1), &p.mg_cin, &p.sh_cin);
     dim3 grid(p.tiles_m * p.tiles_n, 1, pl.splits);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
