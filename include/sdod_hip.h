@@ -95,6 +95,10 @@ SDOD_API size_t sdod_gemm_workspace_bytes(const sdod_gemm_desc* d);
 SDOD_API int sdod_gemm_plan(const sdod_gemm_desc* d, int* tile, int* splits);
 /* developer aid: average duration in ms of `iters` back-to-back launches (HIP events on `stream`) */
 SDOD_API int sdod_gemm_time(const sdod_gemm_desc* d, void* stream, int iters, float* ms_avg);
+/* Same, with cold caches: before every timed launch a sweep of `scratch` (>= 64 MiB; use >= 512 MiB to clear the 256 MiB
+ * Infinity Cache) evicts the weights, then the activation operands are re-read so that they are cache-resident as they are
+ * behind a producer launch.  This is what a GEMM meets inside a graph replay; the engine's tile autotuner ranks with it. */
+SDOD_API int sdod_gemm_time_cold(const sdod_gemm_desc* d, void* stream, int iters, void* scratch, size_t scratch_bytes, float* ms_avg);
 
 /* GroupNorm over NHWC [N][HW][C] (optionally the channel concat of x (c0) and x2 (c1)), G groups,
  * y = (x-mean)*rstd*w+b, optional SiLU.  dtype applies to x and y; weight/bias fp32 or NULL.

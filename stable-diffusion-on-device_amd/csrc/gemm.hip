@@ -50,7 +50,8 @@ struct GemmP {
     int tc0, tc1;
     const float* bias2;
     unsigned mg_hw, sh_hw, mg_w, sh_w, mg_tn, sh_tn, mg_cin, sh_cin; // magic multipliers: m/(h_out*w_out), rem/w_out, lid/tiles_n, k0/cin
-    int dbg;           // developer ablation switches (SDOD_GEMM_DEBUG): 1 = skip MFMAs, 2 = skip DMA after the prologue, 4 = skip fragment reads
+    int dbg;           // ablation switches, honoured only by -DSDOD_GEMM_ABLATE builds (env SDOD_GEMM_DEBUG): 1 = skip MFMAs,
+                       // 2 = skip DMA after the prologue, 4 = skip fragment reads
     int ln;            // LayerNorm of the A rows folded into this GEMM (row statistics gathered from the LDS slabs)
     const float* ln_s;
     float ln_eps;
@@ -335,6 +336,13 @@ SDOD_DEVICE void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// wait until at most `y` slabs (y <= Y, wave-uniform) of LOADS DMA instructions each are still in flight
+template <int LOADS, int Y>
+SDOD_DEVICE void wait_younger(int y) {
+    if (y >= Y) wait_vmcnt<LOADS * Y>();
+    else if constexpr (Y > 0) wait_younger<LOADS, Y - 1>(y);
+}
+
 template <int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, const f16* __restrict__ zeros) {
     constexpr int NW = WM * WN;                   // waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD, so one
@@ -351,6 +359,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f16* smem = reinterpret_cast<f16*>(smem_raw);
+#ifdef SDOD_GEMM_ABLATE
+    const int dbg = p.dbg; // developer build only: the run-time switches keep the accumulators live across branches
+#else
+    constexpr int dbg = 0;
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -498,10 +511,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
 
     for (int it = 0; it < nkt; ++it) {
         // slab `it` has landed once at most the younger in-flight slabs remain outstanding
-        const int younger = min(STAGES - 2, nkt - 1 - it);
-        if (younger >= STAGES - 2 && STAGES > 2) wait_vmcnt<LOADS * (STAGES - 2)>();
-        else if (younger == 1 && STAGES > 3) wait_vmcnt<LOADS>();
-        else wait_vmcnt<0>();
+        wait_younger<LOADS, STAGES - 2>(nkt - 1 - it);
         __builtin_amdgcn_s_barrier(); // everyone's slab `it` is in LDS; everyone is done reading slab it-1
 
         // fragment reads for the whole slab first, then the DMA issue for slab it+STAGES-1 (its address arithmetic and
@@ -509,7 +519,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
         const f16* sA = smem + (it % STAGES) * STAGE;
         const f16* sB = sA + BM * 64;
         f16x8 xa[2][TM], wb[2][TN];
-        if (!(p.dbg & 4)) {
+        if (!(dbg & 4)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -543,8 +553,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
                 }
             }
         }
-        if (it + STAGES - 1 < nkt && !(p.dbg & 2)) issue_tile(kt_begin + it + STAGES - 1, (it + STAGES - 1) % STAGES);
-        if (!(p.dbg & 1)) {
+        if (it + STAGES - 1 < nkt && !(dbg & 2)) issue_tile(kt_begin + it + STAGES - 1, (it + STAGES - 1) % STAGES);
+        if (!(dbg & 1)) {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -741,12 +751,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
 struct TileCfg {
     int bm, bn;
 };
-// id 1..5: register-staged kernel; 6..8: LDS-DMA ring kernel (v2)
-// 9..12: v2 with 8 waves (2 per SIMD)
+// id 1..5: register-staged kernel; 6..8: LDS-DMA ring kernel (v2), 4 waves; 9..16: v2 with 8 waves (2 per SIMD);
+// 17..20: deep rings for the weight-streaming layers (small M, weights from HBM: bytes in flight per CU is what counts)
 const TileCfg kTiles[] = {{0, 0},     {128, 128}, {128, 64}, {64, 64},   {256, 16}, {64, 128}, {128, 128},
                           {128, 64},  {64, 64},   {128, 128}, {256, 128}, {128, 64}, {256, 64},
-                          {128, 128}, {128, 128}, {256, 128}, {256, 256}};
-constexpr int kNumTiles = 16;
+                          {128, 128}, {128, 128}, {256, 128}, {256, 256}, {64, 64},  {128, 64}, {64, 128}, {128, 256}};
+constexpr int kNumTiles = 20;
 
 const f16* zero_line() {
     static f16* z = nullptr;
@@ -921,7 +931,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         p.sa0 = d->lda; p.sa1 = 0;
     }
     const Plan pl = make_plan(d);
-    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln) || pl.tile >= 6, "geglu / tail segment / bias2 / ln need an LDS-DMA tile (6..16)");
+    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln) || pl.tile >= 6, "geglu / tail segment / bias2 / ln need an LDS-DMA tile (6..20)");
     p.splits = pl.splits;
     p.kt_per_split = pl.kt_per_split;
     if (pl.splits > 1) {
@@ -955,7 +965,11 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     case 13: e = launch_glds<128, 128, 2, 4, 4>(p, grid, st); break;
     case 14: e = launch_glds<128, 128, 2, 4, 2>(p, grid, st); break;
     case 15: e = launch_glds<256, 128, 4, 2, 3>(p, grid, st); break;
-    default: e = launch_glds<256, 256, 2, 4, 2>(p, grid, st); break;
+    case 16: e = launch_glds<256, 256, 2, 4, 2>(p, grid, st); break;
+    case 17: e = launch_glds<64, 64, 2, 2, 8>(p, grid, st); break;
+    case 18: e = launch_glds<128, 64, 2, 2, 6>(p, grid, st); break;
+    case 19: e = launch_glds<64, 128, 2, 2, 6>(p, grid, st); break;
+    default: e = launch_glds<128, 256, 2, 4, 3>(p, grid, st); break;
     }
     SDOD_HIP_CHECK(e);
     if (pl.splits > 1) {
@@ -994,6 +1008,72 @@ extern "C" int sdod_gemm_time(const sdod_gemm_desc* d, void* stream, int iters, 
     *ms_avg = ms / iters;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    return 0;
+    SDOD_CATCH
+}
+
+// ---- cold-cache timing.  Inside a graph replay every GEMM finds its WEIGHTS in HBM (the UNet's 1.7 GB of fp16 weights
+// sweep the 256 MiB Infinity Cache many times per evaluation) while its activations were written by the previous launch
+// and are still in L2 / Infinity Cache.  Back-to-back launches of one descriptor measure the opposite (weights hot), which
+// mis-ranks tile shapes for the weight-streaming layers.  So: sweep a scratch buffer larger than the caches (read + write),
+// re-touch the activation operands, then time ONE launch; repeat.
+namespace {
+__global__ __launch_bounds__(256) void cache_sweep_kernel(float4* buf, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float4 v = buf[i];
+        v.x += 1.0f;
+        buf[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void touch_kernel(const float4* a, size_t n, float* sink) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float4 v = a[i];
+        acc += v.x + v.y + v.z + v.w;
+    }
+    if (acc == 1.2345e38f) *sink = acc; // never true; keeps the loads
+}
+void touch(const void* ptr, size_t bytes, float* sink, hipStream_t st) {
+    if (!ptr || bytes < 16) return;
+    const size_t n = bytes / 16;
+    int blocks = (int)std::min<size_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(touch_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)ptr, n, sink);
+}
+} // namespace
+
+extern "C" int sdod_gemm_time_cold(const sdod_gemm_desc* d, void* stream, int iters, void* scratch, size_t scratch_bytes,
+                                   float* ms_avg) {
+    SDOD_TRY
+    SDOD_REQUIRE(d && ms_avg && iters > 0 && iters <= 16, "bad argument");
+    SDOD_REQUIRE(scratch && scratch_bytes >= ((size_t)64 << 20) && ((uintptr_t)scratch & 15) == 0, "scratch must be >= 64 MiB, 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = sdod_gemm_f16(d, stream); // code load, LDS attribute, argument checks
+    if (rc) return rc;
+    hipEvent_t ev[32];
+    for (int i = 0; i < 2 * iters; ++i) SDOD_HIP_CHECK(hipEventCreate(&ev[i]));
+    float* sink = (float*)scratch;
+    const size_t a_bytes = d->a_mode == SDOD_A_ROWS ? (size_t)d->M * d->lda * 2 : (size_t)d->n_img * d->h_in * d->w_in * d->c0 * 2;
+    for (int i = 0; i < iters; ++i) {
+        hipLaunchKernelGGL(cache_sweep_kernel, dim3(2048), dim3(256), 0, st, (float4*)scratch, scratch_bytes / 16);
+        touch(d->a, a_bytes, sink, st);
+        if (d->a2 && d->c1) touch(d->a2, (size_t)d->n_img * d->h_in * d->w_in * d->c1 * 2, sink, st);
+        if (d->residual) touch(d->residual, (size_t)d->M * d->ldr * 2, sink, st);
+        if (d->t0 && d->k_tail) touch(d->t0, (size_t)d->M * d->tc0 * 2, sink, st);
+        if (d->t1 && d->k_tail && d->tc1) touch(d->t1, (size_t)d->M * d->tc1 * 2, sink, st);
+        SDOD_HIP_CHECK(hipEventRecord(ev[2 * i], st));
+        rc = sdod_gemm_f16(d, stream);
+        if (rc) return rc;
+        SDOD_HIP_CHECK(hipEventRecord(ev[2 * i + 1], st));
+    }
+    SDOD_HIP_CHECK(hipEventSynchronize(ev[2 * iters - 1]));
+    float tot = 0.f;
+    for (int i = 0; i < iters; ++i) {
+        float ms = 0.f;
+        SDOD_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+        tot += ms;
+    }
+    for (int i = 0; i < 2 * iters; ++i) (void)hipEventDestroy(ev[i]);
+    *ms_avg = tot / iters;
     return 0;
     SDOD_CATCH
 }

@@ -46,7 +46,7 @@ def workspace(nbytes, device, tag='default'):
 
 def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=None, alpha=1.0, out=None,
          conv=None, a2=None, bias_on_m=False, split_k=0, tile=0, time_iters=0, geglu=False, tail=None, bias2=None,
-         ln_s=None, ln_eps=1e-5):
+         ln_s=None, ln_eps=1e-5, cold_scratch=None):
     """out = act(alpha * A @ W^T + bias + row_bias) + residual.
 
     a: fp16 [M, K] (rows mode) or NHWC [N, H, W, C0] with conv=dict(stride=1|2, upsample=bool) (3x3 pad 1);
@@ -119,7 +119,11 @@ def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=N
         d.workspace = _p(ws); d.workspace_bytes = ws.numel() * 4
     if time_iters:
         ms = ctypes.c_float()
-        check(lib.sdod_gemm_time(ctypes.byref(d), _stream(), time_iters, ctypes.byref(ms)))
+        if cold_scratch is not None:   # cold weights, warm activations: what the launch meets inside a graph replay
+            check(lib.sdod_gemm_time_cold(ctypes.byref(d), _stream(), min(time_iters, 16), _p(cold_scratch),
+                                          cold_scratch.numel() * cold_scratch.element_size(), ctypes.byref(ms)))
+        else:
+            check(lib.sdod_gemm_time(ctypes.byref(d), _stream(), time_iters, ctypes.byref(ms)))
         return ms.value
     check(lib.sdod_gemm_f16(ctypes.byref(d), _stream()))
     return out

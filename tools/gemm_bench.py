@@ -47,10 +47,12 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--only', default='')
     ap.add_argument('--split', type=int, default=0, help='force split-K factor (0 = auto)')
+    ap.add_argument('--cold', action='store_true', help='sweep the caches before every timed launch (weights from HBM)')
     args = ap.parse_args()
     tiles = [int(t) for t in args.tiles.split(',')]
     d = torch.device('cuda:0')
     g = torch.Generator(device='cpu').manual_seed(0)
+    scratch = torch.zeros(512 << 20, dtype=torch.uint8, device=d) if args.cold else None
     print(f'{"shape":28s} {"GFLOP":>8s} ' + ' '.join(f'{"t" + str(t) + " us":>9s} {"TF/s":>7s}' for t in tiles), flush=True)
     for name, kind, prm in SHAPES:
         if args.only and args.only not in name:
@@ -61,7 +63,7 @@ def main():
             w = (torch.randn(n, k, generator=g) * k ** -0.5).half().to(d)
             bias = torch.randn(n).to(d)
             fl = 2.0 * m * n * k
-            call = lambda t, it=0: ops.gemm(a, w, bias, tile=t, time_iters=it, split_k=args.split)
+            call = lambda t, it=0: ops.gemm(a, w, bias, tile=t, time_iters=it, split_k=args.split, cold_scratch=scratch)
         else:
             nb, h, wd, cin, cout, stride, ups = prm
             a = torch.randn(nb, h, wd, cin, generator=g).half().to(d)
@@ -69,7 +71,7 @@ def main():
             bias = torch.randn(cout).to(d)
             ho = (h * (2 if ups else 1)) // stride
             fl = 2.0 * nb * ho * ho * cout * 9 * cin
-            call = lambda t, it=0: ops.gemm(a, w, bias, conv=dict(stride=stride, upsample=ups), tile=t, time_iters=it, split_k=args.split)
+            call = lambda t, it=0: ops.gemm(a, w, bias, conv=dict(stride=stride, upsample=ups), tile=t, time_iters=it, split_k=args.split, cold_scratch=scratch)
         row = f'{name:28s} {fl / 1e9:8.2f} '
         for t in tiles:
             us = call(t, args.iters) * 1e3   # timed inside the library: back-to-back launches, HIP events

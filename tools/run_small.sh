@@ -1,3 +1,4 @@
 export PYTHONUNBUFFERED=1
-for sp in 0 6 10 20 40; do echo "== split $sp"; timeout -k 10 120 python tools/gemm_bench.py --tiles 3,8,2,7,11,5,9,13,14,16 --iters 20 --split $sp --only "1280 @8" 2>&1 | grep -v amdgpu; done
-for sp in 0 3 6 12; do echo "== split $sp"; timeout -k 10 120 python tools/gemm_bench.py --tiles 3,8,2,7,11,5,9,13,14,16 --iters 20 --split $sp --only "1280->1280 @16" 2>&1 | grep -v amdgpu; done
+echo "== cold autotune" && timeout -k 10 500 python bench.py --no-cpu-baseline --steps 3 --warmup 1 2>gpurun_out/bench_cold.err | tail -1 | tee gpurun_out/bench_cold.json &&
+echo "== hot autotune" && SDOD_AUTOTUNE=hot timeout -k 10 500 python bench.py --no-cpu-baseline --steps 3 --warmup 1 2>gpurun_out/bench_hot.err | tail -1 | tee gpurun_out/bench_hot.json &&
+timeout -k 10 300 python tools/unet_profile.py unet --top 60 > gpurun_out/unet_prof6.txt 2>&1
