@@ -44,7 +44,8 @@ Graph::Graph(int kind, const sdod_model_config& cfg, int batch) : kind_(kind), c
     mode_ = DECLARE;
     arena_reset();
     build();
-    allocate_weights();
+    // the parameter table is complete and readable without a device (checkpoint conversion runs on CPU-only hosts);
+    // device memory is claimed by the first set_param / load_file / finalize
 }
 
 Graph::~Graph() {
@@ -122,6 +123,7 @@ int Graph::Pc(const std::string& name, std::vector<int64_t> shape, ParamKind kin
 }
 
 void Graph::allocate_weights() {
+    if (weight_base_) return;
     // groups first (members contiguous, declaration order), then everything else; 256-byte alignment per block
     size_t off = 0;
     std::vector<size_t> offs(params_.size(), 0);
@@ -210,6 +212,7 @@ static void pack_param_host(const Param& p, const S* src, char* dst_raw) {
 }
 
 void Graph::set_param(const std::string& name, const void* data, int dtype, const int64_t* shape, int ndim) {
+    allocate_weights();
     SDOD_REQUIRE(!finalized_, "parameters cannot change after finalize() (weights are repacked / folded in place)");
     auto it = pindex_.find(name);
     SDOD_REQUIRE(it != pindex_.end(), "unknown parameter '" + name + "'");
@@ -249,6 +252,7 @@ void Graph::set_param(const std::string& name, const void* data, int dtype, cons
 // .sdodw container: "SDODW001", u64 count, then per tensor {u32 name_len, name, u32 dtype, u32 ndim, u64 dims[ndim],
 // u64 offset, u64 nbytes}; payloads at absolute file offsets.  Written by sdod.amd.weights.save().
 void Graph::load_file(const std::string& path, const std::string& prefix) {
+    allocate_weights();
     int fd = ::open(path.c_str(), O_RDONLY);
     SDOD_REQUIRE(fd >= 0, "cannot open weight file " + path);
     struct stat stt;
@@ -619,6 +623,7 @@ void Graph::build() {
 }
 
 void Graph::finalize() {
+    allocate_weights();
     SDOD_REQUIRE(!finalized_, "graph already finalized");
     std::string missing;
     int nmiss = 0;

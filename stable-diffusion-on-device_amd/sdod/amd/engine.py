@@ -1,5 +1,6 @@
 """ctypes wrapper of the graph-level C ABI (include/sdod_engine.h): the MI355X stand-in for the reference's
 QnnGraph objects (context.cpp:105 loads unet / text_encoder / vae_decoder / temb; :201-221 wires their I/O)."""
+import contextlib
 import ctypes
 
 import numpy as np
@@ -70,16 +71,21 @@ def device_view(ptr, shape, dtype, device):
 
 
 class Graph:
-    """One compiled graph: parameters in, I/O slots as torch views, execute() on the current stream."""
+    """One compiled graph: parameters in, I/O slots as torch views, execute() on the current stream.
+    Without a GPU only the parameter table can be read (what the checkpoint converter needs); everything that touches
+    device memory raises."""
 
     def __init__(self, kind, cfg, batch, device='cuda:0'):
         self._lib = _engine()
         self._h = ctypes.c_void_p()
         self.kind, self.cfg, self.batch = kind, cfg, batch
         self.device = torch.device(device)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             check(self._lib.sdod_graph_create(ctypes.byref(self._h), kind, ctypes.byref(cfg), batch))
         self.finalized = False
+
+    def _on_device(self):
+        return torch.cuda.device(self.device) if torch.cuda.is_available() else contextlib.nullcontext()
 
     def __del__(self):
         h = getattr(self, '_h', None)

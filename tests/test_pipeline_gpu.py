@@ -96,3 +96,25 @@ def test_pipeline_is_deterministic_and_sharding_invariant(rig):
     a = pipe.generate(ctx2, x, steps=4, guidance=7.5, sampler='plms')
     b = pipe.generate(ctx2, x, steps=4, guidance=7.5, sampler='plms')
     assert torch.equal(a, b)
+
+
+def test_config4_dpm_50_steps_two_images_per_gpu(rig, oracle_lib):
+    """BASELINE config 4 on one rank's share: 50-step DPM, 2 images per GPU (UNet batch 4 = 2 x (uncond, cond)), distinct
+    x_T per image index; every image must match the oracle run of that image alone (sharding changes nothing)."""
+    from oracle import pipeline_oracle as PO
+    from sdod.amd.pipeline import Txt2Img, initial_latent, shard_images
+    pipe1, unet, vae, clip = rig
+    pipe = Txt2Img(state_dicts=pipe1._sd, images_per_gpu=2, latent_hw=16, with_text_encoder=False)
+    ctx2, _ = _ctx(pipe1, clip)
+    mine = shard_images(16, 3, 8)                     # rank 3 of 8 owns images 6 and 7
+    x_T = torch.cat([initial_latent(7, i, (4, 16, 16)) for i in mine], 0)
+    z = pipe.sample_dpm(ctx2, x_T, steps=50, guidance=7.5)
+    assert z.shape == (2, 4, 16, 16) and torch.isfinite(z).all()
+    c16 = ctx2.float().cpu()
+    for j in range(2):
+        z_ref = PO.dpm_sample(unet, oracle_lib, c16[0:1], c16[1:2], x_T[j:j + 1], steps=50, guidance=7.5)
+        r = rel_l2(z[j:j + 1].cpu(), z_ref)
+        print(f'config 4, image {mine[j]}: dpm-50 final latent rel-L2', r)
+        assert r <= 2e-2, r
+    img = pipe.decode(z, mode=0)
+    assert img.shape == (2, 128, 128, 3) and img.dtype == torch.uint8
