@@ -60,8 +60,12 @@ KERNEL_SYMBOLS = {
     'gemm_t6': 'gemm_glds_kernel<128, 128, 2, 2, 3>', 'gemm_t7': 'gemm_glds_kernel<128, 64, 2, 2, 4>',
     'gemm_t8': 'gemm_glds_kernel<64, 64, 2, 2, 4>', 'gemm_t9': 'gemm_glds_kernel<128, 128, 2, 4, 3>',
     'gemm_t10': 'gemm_glds_kernel<256, 128, 4, 2, 2>', 'gemm_t11': 'gemm_glds_kernel<128, 64, 4, 2, 4>',
-    'gemm_t12': 'gemm_glds_kernel<256, 64, 4, 2, 3>', 'gemm_t14': 'gemm_glds_kernel<128, 128, 2, 4, 2>',
-    'gemm_t16': 'gemm_glds_kernel<256, 256, 2, 4, 2>', 'attn_d40': 'attn_kernel<40, 2, true>',
+    'gemm_t12': 'gemm_glds_kernel<256, 64, 4, 2, 3>', 'gemm_t13': 'gemm_glds_kernel<128, 128, 2, 4, 4>',
+    'gemm_t14': 'gemm_glds_kernel<128, 128, 2, 4, 2>', 'gemm_t15': 'gemm_glds_kernel<256, 128, 4, 2, 3>',
+    'gemm_t16': 'gemm_glds_kernel<256, 256, 2, 4, 2>', 'gemm_t17': 'gemm_glds_kernel<64, 64, 2, 2, 8>',
+    'gemm_t18': 'gemm_glds_kernel<128, 64, 2, 2, 6>', 'gemm_t19': 'gemm_glds_kernel<64, 128, 2, 2, 6>',
+    'gemm_t20': 'gemm_glds_kernel<128, 256, 2, 4, 3>', 'gemm_t21': 'gemm_glds_kernel<64, 160, 2, 2, 4>',
+    'gemm_t22': 'gemm_glds_kernel<32, 160, 2, 2, 6>', 'attn_d40': 'attn_kernel<40, 2, true>',
     'attn_d80': 'attn_kernel<80, 1, true>', 'attn_d160': 'attn_kernel<160, 1, true>',
 }
 
@@ -175,6 +179,8 @@ def main():
         log(f'per-UNet-step {unet_step_ms:.3f} ms; profiling the launch list')
         table = pipe.unet.op_table()
         ms = pipe.unet.profile(iters=3)
+        # one family per KERNEL SYMBOL: every launch-list entry is exactly one kernel (a split-K GEMM is two entries, the
+        # GEMM proper and `splitk_reduce`), so the per-launch average is comparable with rocprofv3's per-symbol average
         fam = {}
         for (label, fl, by), t in zip(table, ms):
             f = fam.setdefault(label, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
@@ -193,10 +199,10 @@ def main():
         # separate passes with tools/pmc_traffic.py and committed under profiles/; null when no measurement matches)
         try:
             tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))['labels']
-            roof['traffic'] = round(tr[dom.replace('_splitk', '')]['hbm_bytes_per_launch'])
+            roof['traffic'] = round(tr[dom]['hbm_bytes_per_launch'])
         except (OSError, ValueError, KeyError):
             pass
-        roof.update(kernel=dom, kernel_symbol=KERNEL_SYMBOLS.get(dom.replace('_splitk', ''), dom),
+        roof.update(kernel=dom, kernel_symbol=KERNEL_SYMBOLS.get(dom, dom),
                     flops_per_launch=round(d['flops'] / d['launches']), algorithmic_bytes_per_launch=round(d['bytes'] / d['launches']),
                     launches_per_unet_eval=d['launches'], avg_launch_us=round(1e3 * d['ms'] / d['launches'], 2),
                     share_of_unet_eval=round(d['ms'] / total_ms, 3), unet_eval_eager_ms=round(total_ms, 3),

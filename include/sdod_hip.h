@@ -86,6 +86,8 @@ typedef struct sdod_gemm_desc {
     int ln;
     const void* ln_s;              /* fp32 [N] */
     float ln_eps;
+    int phase;                     /* split-K only: 0 = GEMM + reduce (default), 1 = GEMM slabs only, 2 = reduce + epilogue only
+                                    * (lets a launch list time / profile the two kernels separately) */
 } sdod_gemm_desc;
 
 SDOD_API int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream);

@@ -384,7 +384,7 @@ IoSlot Graph::io(bool output, int index) const {
 // launch meets inside a replay: the UNet's weights are 1.7 GB, the Infinity Cache 256 MiB.  SDOD_AUTOTUNE=0 disables the
 // tuner (gemm.hip's static heuristic decides), SDOD_AUTOTUNE=hot ranks with back-to-back launches instead.
 namespace {
-const int kCandidates[] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20};
+const int kCandidates[] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22};
 
 struct ShapeKey {
     int v[12];
@@ -402,7 +402,7 @@ bool autotune_cold() {
     const char* e = std::getenv("SDOD_AUTOTUNE");
     return !(e && e[0] == 'h');
 }
-constexpr size_t kSweepBytes = (size_t)512 << 20;
+constexpr size_t kSweepBytes = (size_t)384 << 20; // > 8 x 4 MiB L2 + 256 MiB Infinity Cache
 // scratch the cold timing sweeps; allocated on first use, released by release_tune_scratch() at the end of finalize()
 void*& tune_scratch() {
     static void* p = nullptr;
@@ -483,7 +483,7 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
     d.workspace_bytes = ws_bytes_;
     int tile = 0, splits = 1;
     (void)sdod_gemm_plan(&d, &tile, &splits);
-    std::string label = "gemm_t" + std::to_string(tile) + (splits > 1 ? "_splitk" : "");
+    std::string label = "gemm_t" + std::to_string(tile); // one label per kernel symbol (tile table in gemm.hip); "xS" in the detail = split-K
     // algorithmic bytes: A read once (conv: the image, not its im2col), W once, out written once (+ residual read)
     double a_bytes = d.a_mode == SDOD_A_ROWS ? (double)d.M * d.K * 2
                                              : (double)d.n_img * d.h_in * d.w_in * (d.c0 + d.c1) * 2;
@@ -491,6 +491,17 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
     std::string detail = (d.a_mode == SDOD_A_ROWS ? std::string("rows") : "conv" + std::to_string(d.ksize) + (d.upsample ? "u" : "") +
                                                                           (d.stride == 2 ? "s2" : "") + (d.c1 ? "+cat" : "")) +
                          " M" + std::to_string(d.M) + " N" + std::to_string(d.N) + " K" + std::to_string(d.K) + " x" + std::to_string(splits);
+    if (splits > 1) {
+        // two launch-list entries, one per kernel, so that per-launch timings line up with rocprofv3's per-symbol numbers
+        sdod_gemm_desc d1 = d, d2 = d;
+        d1.phase = 1;
+        d2.phase = 2;
+        const double part = (double)splits * d.M * d.N * 4;
+        sink().push_back(Op{[d1](hipStream_t st) { check_rc(sdod_gemm_f16(&d1, st)); }, label, fl, by + part, detail});
+        sink().push_back(Op{[d2](hipStream_t st) { check_rc(sdod_gemm_f16(&d2, st)); }, "splitk_reduce", 0.0,
+                            part + (double)d.M * d.N * 2 * (d.residual ? 2 : 1), detail});
+        return;
+    }
     sink().push_back(Op{[d](hipStream_t st) { check_rc(sdod_gemm_f16(&d, st)); }, label, fl, by, detail});
 }
 

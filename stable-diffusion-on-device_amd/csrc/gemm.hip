@@ -50,8 +50,6 @@ struct GemmP {
     int tc0, tc1;
     const float* bias2;
     unsigned mg_hw, sh_hw, mg_w, sh_w, mg_tn, sh_tn, mg_cin, sh_cin; // magic multipliers: m/(h_out*w_out), rem/w_out, lid/tiles_n, k0/cin
-    int dbg;           // ablation switches, honoured only by -DSDOD_GEMM_ABLATE builds (env SDOD_GEMM_DEBUG): 1 = skip MFMAs,
-                       // 2 = skip DMA after the prologue, 4 = skip fragment reads
     int ln;            // LayerNorm of the A rows folded into this GEMM (row statistics gathered from the LDS slabs)
     const float* ln_s;
     float ln_eps;
@@ -360,7 +358,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f16* smem = reinterpret_cast<f16*>(smem_raw);
 #ifdef SDOD_GEMM_ABLATE
-    const int dbg = p.dbg; // developer build only: the run-time switches keep the accumulators live across branches
+    constexpr int dbg = SDOD_GEMM_ABLATE; // developer builds only (Makefile: lib/libsdod_abl<mask>.so)
 #else
     constexpr int dbg = 0;
 #endif
@@ -509,6 +507,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
         if (s < nkt) issue_tile(kt_begin + s, s);
     }
 
+    // per-column epilogue vectors (bias, bias2, LayerNorm-fold s) -> LDS, once per workgroup and coalesced, while the first
+    // slabs are in flight: the epilogue then has no dependent global loads left (they used to be one L2 round trip per
+    // accumulator element).  Columns past N read 0.  Made visible by the barriers of the main loop / before the epilogue.
+    constexpr size_t RING_BYTES = (size_t)STAGES * STAGE * sizeof(f16);
+    constexpr size_t CTILE_BYTES = (size_t)BM * SC * sizeof(f16) + (size_t)BM * 2 * sizeof(float);
+    float* colv = reinterpret_cast<float*>(smem_raw + (RING_BYTES > CTILE_BYTES ? RING_BYTES : CTILE_BYTES)); // [3][BN]
+    for (int c = tid; c < BN; c += NT) {
+        const int n = n0 + c;
+        const bool ok = n < p.N;
+        colv[c] = (ok && p.bias != nullptr && !p.bias_on_m) ? p.bias[n] : 0.f;
+        colv[BN + c] = (ok && p.bias2 != nullptr) ? p.bias2[n] : 0.f;
+        colv[2 * BN + c] = (ok && p.ln) ? p.ln_s[n] : 0.f;
+    }
+
     for (int it = 0; it < nkt; ++it) {
         // slab `it` has landed once at most the younger in-flight slabs remain outstanding
         wait_younger<LOADS, STAGES - 2>(nkt - 1 - it);
@@ -624,27 +636,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
     if (p.geglu) {
         // 16-column blocks alternate [value | gate]; both live in the SAME lane (acc[i][j], acc[i][j+1]), so GEGLU is a
         // register-level product and the tile that goes to memory is half as wide
-        if constexpr (TN % 2 == 0) {
+        if constexpr (TN % 2 == 0) { // odd-TN tiles (21, 22) never get a GEGLU descriptor: make_plan + the host check
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int ml = wm * WTM + i * 16 + e_m;
 #pragma unroll
                 for (int j = 0; j < TN; j += 2) {
                     const int nl = wn * WTN + j * 16 + e_n; // column of the value block in W-row space
-                    const int n = n0 + nl;
                     f16x4 h;
+                    const f32x4 ba = *reinterpret_cast<const f32x4*>(colv + nl), bg = *reinterpret_cast<const f32x4*>(colv + nl + 16);
+                    const f32x4 sa = *reinterpret_cast<const f32x4*>(colv + 2 * BN + nl), sg = *reinterpret_cast<const f32x4*>(colv + 2 * BN + nl + 16);
+                    const float mean = p.ln ? ln_stats[2 * ml] : 0.f, rstd = p.ln ? ln_stats[2 * ml + 1] : 1.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float va = acc[i][j][r] * p.alpha, vg = acc[i][j + 1][r] * p.alpha;
-                        if (p.ln && n + 16 + r < p.N) {
-                            const float mean = ln_stats[2 * ml], rstd = ln_stats[2 * ml + 1];
-                            va = rstd * (va - mean * p.ln_s[n + r]);
-                            vg = rstd * (vg - mean * p.ln_s[n + 16 + r]);
+                        if (p.ln) {
+                            va = rstd * (va - mean * sa[r]);
+                            vg = rstd * (vg - mean * sg[r]);
                         }
-                        if (p.bias != nullptr && n + 16 + r < p.N) {
-                            va += p.bias[n + r];
-                            vg += p.bias[n + 16 + r];
-                        }
+                        va += ba[r];
+                        vg += bg[r];
                         h[r] = (f16)(va * gelu_erf_f(vg));
                     }
                     *reinterpret_cast<f16x4*>(sC + ml * SC + (wn * WTN + j * 16) / 2 + e_n) = h;
@@ -663,19 +674,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
             const int nl = wn * WTN + j * 16 + e_n;
             const int n = n0 + nl;
             f16x4 h;
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(colv + nl), b2 = *reinterpret_cast<const f32x4*>(colv + BN + nl);
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(colv + 2 * BN + nl);
+            float rb[4] = {0.f, 0.f, 0.f, 0.f};
+            if (rbias != nullptr) {
+                if (n + 3 < p.N && (p.ldrb & 3) == 0 && ((uintptr_t)p.row_bias & 7) == 0) {
+                    const f16x4 t = *reinterpret_cast<const f16x4*>(rbias + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rb[r] = (float)t[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N) rb[r] = (float)rbias[n + r];
+                }
+            }
+            const float mean = p.ln ? ln_stats[2 * ml] : 0.f, rstd = p.ln ? ln_stats[2 * ml + 1] : 1.f;
+            const float bm = (p.bias != nullptr && p.bias_on_m && m < p.M) ? p.bias[m] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = acc[i][j][r] * p.alpha;
-                if (p.ln && n + r < p.N) v = ln_stats[2 * ml + 1] * (v - ln_stats[2 * ml] * p.ln_s[n + r]);
-                if (p.bias != nullptr) {
-                    if (p.bias_on_m) {
-                        if (m < p.M) v += p.bias[m];
-                    } else if (n + r < p.N) {
-                        v += p.bias[n + r];
-                    }
-                }
-                if (p.bias2 != nullptr && n + r < p.N) v += p.bias2[n + r];
-                if (rbias != nullptr && n + r < p.N) v += (float)rbias[n + r];
+                if (p.ln) v = rstd * (v - mean * sv[r]);
+                v += b1[r];
+                if (p.bias_on_m) v += bm;
+                v += b2[r];
+                if (rbias != nullptr) v += rb[r];
                 v = apply_act(v, p.act);
                 h[r] = (f16)v;
             }
@@ -753,10 +775,13 @@ struct TileCfg {
 };
 // id 1..5: register-staged kernel; 6..8: LDS-DMA ring kernel (v2), 4 waves; 9..16: v2 with 8 waves (2 per SIMD);
 // 17..20: deep rings for the weight-streaming layers (small M, weights from HBM: bytes in flight per CU is what counts)
+// 21..22: 160-column tiles: N = 320 / 640 / 1280 divide without the 17 % padding a 128-wide tile pays at N = 320, and
+//         M = 8192 x N = 320 becomes exactly 256 workgroups (one per CU)
 const TileCfg kTiles[] = {{0, 0},     {128, 128}, {128, 64}, {64, 64},   {256, 16}, {64, 128}, {128, 128},
                           {128, 64},  {64, 64},   {128, 128}, {256, 128}, {128, 64}, {256, 64},
-                          {128, 128}, {128, 128}, {256, 128}, {256, 256}, {64, 64},  {128, 64}, {64, 128}, {128, 256}};
-constexpr int kNumTiles = 20;
+                          {128, 128}, {128, 128}, {256, 128}, {256, 256}, {64, 64},  {128, 64}, {64, 128}, {128, 256},
+                          {64, 160},  {32, 160}};
+constexpr int kNumTiles = 22;
 
 const f16* zero_line() {
     static f16* z = nullptr;
@@ -771,7 +796,7 @@ template <int BM, int BN, int WM, int WN, int STAGES>
 hipError_t launch_glds(const GemmP& p, dim3 grid, hipStream_t st) {
     constexpr size_t ring = (size_t)STAGES * (BM + BN) * 64 * sizeof(f16);
     constexpr size_t ctile = (size_t)BM * (BN + 8) * sizeof(f16) + (size_t)BM * 2 * sizeof(float); // + LayerNorm row stats
-    constexpr size_t smem = ring > ctile ? ring : ctile;
+    constexpr size_t smem = (ring > ctile ? ring : ctile) + (size_t)3 * BN * sizeof(float); // + per-column epilogue vectors
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, STAGES>),
@@ -812,6 +837,7 @@ Plan make_plan(const sdod_gemm_desc* d) {
     int tile = d->tile;
     const bool fused = d->geglu || d->k_tail || d->ln;
     if (fused && (tile < 6 || tile > kNumTiles)) tile = 14; // fusions live in the LDS-DMA kernel family only
+    if (d->geglu && (tile == 21 || tile == 22)) tile = 14;  // value/gate pairing needs an even number of 16-column blocks per wave
     if (tile <= 0 || tile > kNumTiles) {
         if (d->N <= 16) {
             tile = 4;
@@ -889,10 +915,6 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     p.k_tail = d->k_tail;
     p.t0 = (const f16*)d->t0; p.t1 = (const f16*)d->t1; p.tc0 = d->tc0; p.tc1 = d->tc1;
     p.bias2 = (const float*)d->bias2;
-    {
-        const char* e = std::getenv("SDOD_GEMM_DEBUG");
-        p.dbg = e ? std::atoi(e) : 0;
-    }
     p.ln = d->ln ? 1 : 0;
     p.ln_s = (const float*)d->ln_s;
     p.ln_eps = d->ln_eps;
@@ -931,7 +953,8 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         p.sa0 = d->lda; p.sa1 = 0;
     }
     const Plan pl = make_plan(d);
-    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln) || pl.tile >= 6, "geglu / tail segment / bias2 / ln need an LDS-DMA tile (6..20)");
+    SDOD_REQUIRE(!(d->geglu && (pl.tile == 21 || pl.tile == 22)), "geglu needs a tile with an even number of 16-column blocks per wave");
+    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln) || pl.tile >= 6, "geglu / tail segment / bias2 / ln need an LDS-DMA tile (6..22)");
     p.splits = pl.splits;
     p.kt_per_split = pl.kt_per_split;
     if (pl.splits > 1) {
@@ -948,7 +971,9 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     make_magic((unsigned)(p.c0 + p.c1), &p.mg_cin, &p.sh_cin);
     dim3 grid(p.tiles_m * p.tiles_n, 1, pl.splits);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e;
+    SDOD_REQUIRE(d->phase >= 0 && d->phase <= 2 && (d->phase == 0 || pl.splits > 1), "phase 1/2 only apply to a split-K plan");
+    hipError_t e = hipSuccess;
+    if (d->phase != 2)
     switch (pl.tile) {
     case 1: e = launch_cfg<128, 128, 2, 2>(p, grid, st); break;
     case 2: e = launch_cfg<128, 64, 2, 2>(p, grid, st); break;
@@ -969,10 +994,12 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     case 17: e = launch_glds<64, 64, 2, 2, 8>(p, grid, st); break;
     case 18: e = launch_glds<128, 64, 2, 2, 6>(p, grid, st); break;
     case 19: e = launch_glds<64, 128, 2, 2, 6>(p, grid, st); break;
-    default: e = launch_glds<128, 256, 2, 4, 3>(p, grid, st); break;
+    case 20: e = launch_glds<128, 256, 2, 4, 3>(p, grid, st); break;
+    case 21: e = launch_glds<64, 160, 2, 2, 4>(p, grid, st); break;
+    default: e = launch_glds<32, 160, 2, 2, 6>(p, grid, st); break;
     }
     SDOD_HIP_CHECK(e);
-    if (pl.splits > 1) {
+    if (pl.splits > 1 && d->phase != 1) {
         const size_t total = (size_t)d->M * ((d->N + 3) / 4);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;

@@ -52,7 +52,7 @@ class GemmDesc(ctypes.Structure):
         ('stride', c_int), ('upsample', c_int), ('ksize', c_int), ('rows_per_img', c_int), ('ld_row_bias', c_int),
         ('act', c_int), ('alpha', c_float), ('bias_on_m', c_int), ('split_k', c_int), ('tile', c_int),
         ('geglu', c_int), ('k_tail', c_int), ('t0', c_void_p), ('t1', c_void_p), ('tc0', c_int), ('tc1', c_int),
-        ('bias2', c_void_p), ('ln', c_int), ('ln_s', c_void_p), ('ln_eps', c_float),
+        ('bias2', c_void_p), ('ln', c_int), ('ln_s', c_void_p), ('ln_eps', c_float), ('phase', c_int),
     ]
 
 

@@ -22,8 +22,10 @@ def op_type(label, detail=''):
         return 'GroupNorm(+SiLU)'
     if label.startswith('layer_norm'):
         return 'LayerNorm'
-    if label.startswith(('softmax',)):
+    if label.startswith('softmax'):
         return 'Softmax'
+    if label.startswith('splitk_reduce'):
+        return 'Split-K reduce + epilogue'
     if label.startswith(('geglu', 'act', 'add', 'silu')):
         return 'Elementwise'
     if label.startswith(('nchw', 'nhwc', 'latent', 'im2col', 'concat', 'embedding', 'timestep')):

@@ -66,7 +66,7 @@ def test_gemm_rows(m, n, k, tile):
     check(out, ref, name=f'gemm {m}x{n}x{k} tile{tile}')
 
 
-@pytest.mark.parametrize('tile', [0, 6, 8, 9, 10, 17, 20])
+@pytest.mark.parametrize('tile', [0, 6, 8, 9, 10, 17, 20, 21, 22])
 @pytest.mark.parametrize('split', [2, 5, 16])
 def test_gemm_split_k(split, tile):
     from sdod.amd import ops
@@ -103,7 +103,7 @@ def conv_ref(x_nhwc, w_krsc, bias, stride=1, upsample=False):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
-@pytest.mark.parametrize('tile', [0, 6, 7, 8, 9, 10, 11, 12, 13, 18, 19, 20])
+@pytest.mark.parametrize('tile', [0, 6, 7, 8, 9, 10, 11, 12, 13, 18, 19, 20, 21, 22])
 @pytest.mark.parametrize('n,h,w,cin,cout,stride,ups', [
     (2, 16, 16, 64, 128, 1, False), (1, 9, 7, 128, 64, 1, False), (2, 16, 16, 64, 64, 2, False),
     (1, 8, 8, 128, 128, 1, True), (2, 64, 64, 320, 320, 1, False), (2, 8, 8, 1280, 1280, 1, False),
@@ -130,7 +130,7 @@ def test_conv3x3_concat_rowbias_residual():
     ref = conv_ref(torch.cat([x0, x1], -1), wt, bias) + rb.float()[:, None, None, :]
     ref = ref.half().float() + res.float()
     d = dev()
-    for tile in (0, 6, 7, 8, 9, 10, 11, 12, 17, 18, 19, 20):
+    for tile in (0, 6, 7, 8, 9, 10, 11, 12, 17, 18, 19, 20, 21, 22):
         out = ops.gemm(x0.to(d), wt.to(d), bias.to(d), a2=x1.to(d), conv=dict(stride=1), row_bias=rb.to(d), rows_per_img=h * w,
                        residual=res.to(d), tile=tile)
         check(out, ref, name=f'conv concat tile{tile}')
@@ -149,9 +149,10 @@ def test_conv1x1_two_sources():
     check(out, ref, name='conv1x1 concat')
 
 
-@pytest.mark.parametrize('tile', [0, 6, 8, 10, 14, 16])
+@pytest.mark.parametrize('tile', [0, 6, 8, 10, 14, 16, 20, 21, 22])
 def test_gemm_fused_geglu(tile):
-    """ff.net.0.proj + GEGLU in one launch: weight rows interleaved in 16-row [value | gate] blocks"""
+    """ff.net.0.proj + GEGLU in one launch: weight rows interleaved in 16-row [value | gate] blocks (tiles 21/22 cannot
+    pair value and gate inside one wave: the planner must fall back, not skip the epilogue)"""
     from sdod.amd import ops
     m, c = 600, 320
     x = rnd((m, c), 90); w = rnd((8 * c, c), 91, c ** -0.5); b = torch.randn(8 * c, generator=torch.Generator().manual_seed(92))
@@ -168,7 +169,7 @@ def test_gemm_fused_geglu(tile):
     check(out, ref, name=f'fused geglu tile{tile}')
 
 
-@pytest.mark.parametrize('tile', [0, 6, 8, 11, 14, 18, 20])
+@pytest.mark.parametrize('tile', [0, 6, 8, 11, 14, 18, 20, 21, 22])
 @pytest.mark.parametrize('m,c,n', [(600, 320, 960), (8192, 320, 320), (200, 1280, 1280)])
 def test_gemm_with_folded_layer_norm(tile, m, c, n):
     """LayerNorm -> Linear in one launch: row statistics gathered inside the GEMM, gamma folded into W"""

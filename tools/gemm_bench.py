@@ -47,8 +47,13 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--only', default='')
     ap.add_argument('--split', type=int, default=0, help='force split-K factor (0 = auto)')
+    ap.add_argument('--lib', default='', help='load lib/<name> instead of libsdod.so (ablation builds, see the Makefile)')
     ap.add_argument('--cold', action='store_true', help='sweep the caches before every timed launch (weights from HBM)')
     args = ap.parse_args()
+    if args.lib:
+        import ctypes
+        from sdod.amd import _lib
+        _lib._cache['libsdod.so'] = ctypes.CDLL(os.path.join(_lib.LIB_DIR, args.lib), mode=ctypes.RTLD_GLOBAL)
     tiles = [int(t) for t in args.tiles.split(',')]
     d = torch.device('cuda:0')
     g = torch.Generator(device='cpu').manual_seed(0)

@@ -1,3 +1,4 @@
-# SDOD_GEMM_DEBUG ablation of the v2 GEMM (1: no MFMA, 2: no DMA after the prologue, 4: no LDS fragment reads)
+# compile-time ablation of the v2 GEMM main loop (make lib/libsdod_abl<mask>.so; 1: no MFMA, 2: no DMA after the
+# prologue, 4: no LDS fragment reads)
 export PYTHONUNBUFFERED=1
-for SP in 1 4 12 30; do for D in 0 5 7; do echo "== split $SP SDOD_GEMM_DEBUG=$D"; for S in "conv 1280->1280 @8" "small M512"; do SDOD_GEMM_DEBUG=$D timeout -k 10 120 python tools/gemm_bench.py --split $SP --tiles 3,8,14,17,20 --iters 30 --only "$S" 2>&1 | grep -v amdgpu | tail -1; done; done; done
+for L in libsdod.so libsdod_abl1.so libsdod_abl4.so libsdod_abl5.so libsdod_abl7.so; do echo "== $L"; for S in "conv 320->320" "conv 640->640 @32" "ff1 320" "vae conv 512"; do timeout -k 10 120 python tools/gemm_bench.py --lib $L --tiles 6,13,14,10,21,8 --iters 20 --only "$S" 2>&1 | grep -v amdgpu | tail -1; done; done

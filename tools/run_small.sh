@@ -1,4 +1,3 @@
 export PYTHONUNBUFFERED=1
-echo "== cold autotune" && timeout -k 10 500 python bench.py --no-cpu-baseline --steps 3 --warmup 1 2>gpurun_out/bench_cold.err | tail -1 | tee gpurun_out/bench_cold.json &&
-echo "== hot autotune" && SDOD_AUTOTUNE=hot timeout -k 10 500 python bench.py --no-cpu-baseline --steps 3 --warmup 1 2>gpurun_out/bench_hot.err | tail -1 | tee gpurun_out/bench_hot.json &&
-timeout -k 10 300 python tools/unet_profile.py unet --top 60 > gpurun_out/unet_prof6.txt 2>&1
+timeout -k 10 900 python -m pytest tests/test_kernels_gpu.py tests/test_engine_gpu.py -x -q 2>&1 | tail -4 &&
+timeout -k 10 500 python bench.py --no-cpu-baseline --steps 3 --warmup 1 2>gpurun_out/bench_c.err | tail -1 > gpurun_out/bench_c.json && cut -c1-300 gpurun_out/bench_c.json
