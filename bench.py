@@ -65,7 +65,8 @@ KERNEL_SYMBOLS = {
     'gemm_t16': 'gemm_glds_kernel<256, 256, 2, 4, 2>', 'gemm_t17': 'gemm_glds_kernel<64, 64, 2, 2, 8>',
     'gemm_t18': 'gemm_glds_kernel<128, 64, 2, 2, 6>', 'gemm_t19': 'gemm_glds_kernel<64, 128, 2, 2, 6>',
     'gemm_t20': 'gemm_glds_kernel<128, 256, 2, 4, 3>', 'gemm_t21': 'gemm_glds_kernel<64, 160, 2, 2, 4>',
-    'gemm_t22': 'gemm_glds_kernel<32, 160, 2, 2, 6>', 'attn_d40': 'attn_kernel<40, 2, true>',
+    'gemm_t22': 'gemm_glds_kernel<32, 160, 2, 2, 6>', 'gn_small': 'gn_small_kernel<f16>',
+    'gn_stats_apply': 'gn_stats_kernel<f16, 1> + gn_apply_kernel<f16>', 'splitk_reduce': 'splitk_reduce_kernel', 'attn_d40': 'attn_kernel<40, 2, true>',
     'attn_d80': 'attn_kernel<80, 1, true>', 'attn_d160': 'attn_kernel<160, 1, true>',
 }
 

@@ -100,12 +100,15 @@ SDOD_API int sdod_gemm_time(const sdod_gemm_desc* d, void* stream, int iters, fl
 /* Same, with cold caches: before every timed launch a sweep of `scratch` (>= 64 MiB; use >= 512 MiB to clear the 256 MiB
  * Infinity Cache) evicts the weights, then the activation operands are re-read so that they are cache-resident as they are
  * behind a producer launch.  This is what a GEMM meets inside a graph replay; the engine's tile autotuner ranks with it. */
-SDOD_API int sdod_gemm_time_cold(const sdod_gemm_desc* d, void* stream, int iters, void* scratch, size_t scratch_bytes, float* ms_avg);
+SDOD_API int sdod_gemm_time_cold(const sdod_gemm_desc* d, void* stream, int iters, void* scratch, size_t scratch_bytes, float* ms_avg,
+                                float* ms_min /* may be NULL */);
 
 /* GroupNorm over NHWC [N][HW][C] (optionally the channel concat of x (c0) and x2 (c1)), G groups,
  * y = (x-mean)*rstd*w+b, optional SiLU.  dtype applies to x and y; weight/bias fp32 or NULL.
  * workspace: >= sdod_group_norm_workspace_bytes(N, G) bytes of fp32 scratch. */
 SDOD_API size_t sdod_group_norm_workspace_bytes(int n, int groups);
+/* 1 = the single-launch kernel (whole image x channel set in LDS) handles this shape, 2 = statistics + apply launches */
+SDOD_API int sdod_group_norm_launches(int hw, int c, int groups, int dtype);
 SDOD_API int sdod_group_norm_nhwc(const void* x, const void* x2, void* y, const float* weight, const float* bias,
                                   int n, int hw, int c0, int c1, int groups, float eps, int silu, int dtype,
                                   void* workspace, void* stream);

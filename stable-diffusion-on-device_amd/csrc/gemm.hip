@@ -1069,7 +1069,7 @@ void touch(const void* ptr, size_t bytes, float* sink, hipStream_t st) {
 } // namespace
 
 extern "C" int sdod_gemm_time_cold(const sdod_gemm_desc* d, void* stream, int iters, void* scratch, size_t scratch_bytes,
-                                   float* ms_avg) {
+                                   float* ms_avg, float* ms_min) {
     SDOD_TRY
     SDOD_REQUIRE(d && ms_avg && iters > 0 && iters <= 16, "bad argument");
     SDOD_REQUIRE(scratch && scratch_bytes >= ((size_t)64 << 20) && ((uintptr_t)scratch & 15) == 0, "scratch must be >= 64 MiB, 16-byte aligned");
@@ -1093,14 +1093,16 @@ extern "C" int sdod_gemm_time_cold(const sdod_gemm_desc* d, void* stream, int it
         SDOD_HIP_CHECK(hipEventRecord(ev[2 * i + 1], st));
     }
     SDOD_HIP_CHECK(hipEventSynchronize(ev[2 * iters - 1]));
-    float tot = 0.f;
+    float tot = 0.f, best = 1e30f;
     for (int i = 0; i < iters; ++i) {
         float ms = 0.f;
         SDOD_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
         tot += ms;
+        best = ms < best ? ms : best;
     }
     for (int i = 0; i < 2 * iters; ++i) (void)hipEventDestroy(ev[i]);
     *ms_avg = tot / iters;
+    if (ms_min) *ms_min = best; // disturbances only ever add time: the minimum is the steadier ranking key
     return 0;
     SDOD_CATCH
 }

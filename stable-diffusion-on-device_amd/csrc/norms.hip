@@ -323,12 +323,19 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GnP p, int sw) {
 
 static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 
+// single-launch path eligibility (also what sdod_group_norm_launches reports)
+static bool gn_small_fits(int hw, int c, int cg, size_t elem) {
+    const int sw = cg / gcd_i(cg, 8) * 8; // lcm(Cg, 8)
+    if (c % sw != 0) return false;
+    const size_t smem = (size_t)hw * sw * elem + ((size_t)2 * sw + 64) * sizeof(float) + (size_t)sw;
+    return hw <= 256 && sw / cg <= 4 && smem <= 96 * 1024;
+}
+
 template <typename T>
 bool gn_try_small(GnP& p, hipStream_t st) {
     const int sw = p.Cg / gcd_i(p.Cg, 8) * 8; // lcm(Cg, 8)
-    if (p.C % sw != 0) return false;
+    if (!gn_small_fits(p.HW, p.C, p.Cg, sizeof(T))) return false;
     const size_t smem = (size_t)p.HW * sw * sizeof(T) + ((size_t)2 * sw + 64) * sizeof(float) + (size_t)sw;
-    if (p.HW > 256 || sw / p.Cg > 4 || smem > 96 * 1024) return false;
     static bool attr_set = false;
     if (!attr_set) {
         SDOD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -469,6 +476,11 @@ extern "C" int sdod_ln_fold_f16(void* w, int n, int k, int ldw, const float* gam
     SDOD_HIP_CHECK(hipGetLastError());
     return 0;
     SDOD_CATCH
+}
+
+extern "C" int sdod_group_norm_launches(int hw, int c, int groups, int dtype) {
+    if (hw <= 0 || c <= 0 || groups <= 0 || c % groups) return 0;
+    return gn_small_fits(hw, c, c / groups, dtype == SDOD_F16 ? 2 : 4) ? 1 : 2; // (+1 collapse launch on very large maps)
 }
 
 extern "C" size_t sdod_group_norm_workspace_bytes(int n, int groups) {

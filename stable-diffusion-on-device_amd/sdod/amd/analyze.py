@@ -18,7 +18,7 @@ def op_type(label, detail=''):
         return 'Linear / MatMul'
     if label.startswith('attn'):
         return 'Attention (QK^T softmax PV)'
-    if label.startswith('group_norm'):
+    if label.startswith(('group_norm', 'gn_')):
         return 'GroupNorm(+SiLU)'
     if label.startswith('layer_norm'):
         return 'LayerNorm'

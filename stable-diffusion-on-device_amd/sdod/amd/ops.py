@@ -121,7 +121,7 @@ def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=N
         ms = ctypes.c_float()
         if cold_scratch is not None:   # cold weights, warm activations: what the launch meets inside a graph replay
             check(lib.sdod_gemm_time_cold(ctypes.byref(d), _stream(), min(time_iters, 16), _p(cold_scratch),
-                                          cold_scratch.numel() * cold_scratch.element_size(), ctypes.byref(ms)))
+                                          cold_scratch.numel() * cold_scratch.element_size(), ctypes.byref(ms), None))
         else:
             check(lib.sdod_gemm_time(ctypes.byref(d), _stream(), time_iters, ctypes.byref(ms)))
         return ms.value
