@@ -56,6 +56,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
     constexpr int DC = D / 8;                // 16-byte chunks per K/V row
     constexpr int LD_IT = (KT * DC + 255) / 256;
     constexpr int STAGE = KT * (KSTR + VSTR);
+    // d = 40: V is padded to 48 columns; a column of ones there makes the PV product accumulate the softmax row sum
+    // (sum of the SAME fp16-rounded probabilities that weight V) -- 16 packed adds per tile and query tile less on the VALU
+    constexpr bool SUM_BY_MFMA = DV > D;
     static_assert(D % 8 == 0, "head dim must be a multiple of 8");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -86,7 +89,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
             if (VPADC > 0)
                 for (int idx = tid; idx < KT * VPADC; idx += 256) {
                     const int row = idx / (VPADC > 0 ? VPADC : 1), ch = idx - row * VPADC;
-                    *reinterpret_cast<f16x8*>(sV + row * VSTR + D + ch * 8) = zero8();
+                    f16x8 pad = zero8();
+                    if (ch == 0) pad[0] = (f16)1.0f; // column D: the row-sum column (SUM_BY_MFMA)
+                    *reinterpret_cast<f16x8*>(sV + row * VSTR + D + ch * 8) = pad;
                 }
         }
     }
@@ -203,7 +208,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float m_new = fmaxf(m_run[a], mx * p.scale_log2); // running max in scaled (log2) units
-            const float alpha = __builtin_amdgcn_exp2f(m_run[a] - m_new);
+            // once the running maxima have settled (a few tiles in) no lane of the wave changes its maximum: skip the
+            // rescale of the output accumulators (wave-uniform branch)
+            const bool rescale = __builtin_amdgcn_ballot_w64(m_new != m_run[a]) != 0;
+            const float alpha = rescale ? __builtin_amdgcn_exp2f(m_run[a] - m_new) : 1.0f;
             m_run[a] = m_new;
             f32x2 rs2 = {0.f, 0.f};
             const f32x2 sc2 = {p.scale_log2, p.scale_log2};
@@ -216,18 +224,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
                     v = v * sc2 + nm2; // packed fma
                     v[0] = __builtin_amdgcn_exp2f(v[0]);
                     v[1] = __builtin_amdgcn_exp2f(v[1]);
-                    rs2 += v;
+                    if (!SUM_BY_MFMA) rs2 += v;
                     s[a][c][2 * h2] = v[0];
                     s[a][c][2 * h2 + 1] = v[1];
                 }
             }
-            l_run[a] = l_run[a] * alpha + (rs2[0] + rs2[1]);
-            const f32x2 al2 = {alpha, alpha};
+            if (!SUM_BY_MFMA) l_run[a] = l_run[a] * alpha + (rs2[0] + rs2[1]);
+            if (rescale) {
+                const f32x2 al2 = {alpha, alpha};
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                f32x2 lo = {o[a][dt][0], o[a][dt][1]}, hi = {o[a][dt][2], o[a][dt][3]};
-                lo *= al2; hi *= al2;
-                o[a][dt][0] = lo[0]; o[a][dt][1] = lo[1]; o[a][dt][2] = hi[0]; o[a][dt][3] = hi[1];
+                for (int dt = 0; dt < NDT; ++dt) {
+                    f32x2 lo = {o[a][dt][0], o[a][dt][1]}, hi = {o[a][dt][2], o[a][dt][3]};
+                    lo *= al2; hi *= al2;
+                    o[a][dt][0] = lo[0]; o[a][dt][1] = lo[1]; o[a][dt][2] = hi[0]; o[a][dt][3] = hi[1];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -270,9 +280,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
     // ---- normalise and store: lane holds O[q = qrow][dv = dt*16 + 4g + r]
 #pragma unroll
     for (int a = 0; a < QT; ++a) {
-        float l = l_run[a];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        float l;
+        if (SUM_BY_MFMA) {
+            // the row sum sits in output column D = (D / 16) * 16 + 4 g + r  ->  lane group g = (D % 16) / 4, register r = D % 4
+            l = __shfl(o[a][D / 16][D % 4], ((D % 16) / 4) * 16 + li);
+        } else {
+            l = l_run[a];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         if (qrow[a] < p.Lq) {
             f16* op = p.out + ((size_t)b * p.Lq + qrow[a]) * p.ldo + h * D;

@@ -12,6 +12,17 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the CPU oracle runs on this process's share of the host: os.cpu_count() reports every core of the machine (256 on a
+    # GPU box whose per-GPU share is 16), and an oversubscribed intra-op pool makes the fp32 oracle several times slower
+    try:
+        import torch
+        try:
+            n = len(os.sched_getaffinity(0))
+        except AttributeError:
+            n = os.cpu_count() or 1
+        torch.set_num_threads(max(1, min(16, n)))
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope='session')
