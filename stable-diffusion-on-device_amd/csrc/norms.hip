@@ -227,19 +227,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnP p) {
 // Small feature maps (the 8x8 / 16x16 / 32x32 levels: 2/3 of the UNet's GroupNorms): ONE launch.  A workgroup owns all
 // pixels of image n for a channel set of `sw` channels (whole groups, 16-byte aligned: sw = lcm(C/G, 8)); the slab is
 // read once into LDS, statistics are an exact two-pass reduction over LDS, then normalise + SiLU + store.
-template <typename T>
-__global__ __launch_bounds__(256) void gn_small_kernel(const GnP p, int sw) {
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void gn_small_kernel(const GnP p, int sw) {
+    constexpr int NWV = NT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* slab = reinterpret_cast<T*>(smem_raw);                               // [HW][sw]
     float* sc = reinterpret_cast<float*>(smem_raw + (size_t)p.HW * sw * sizeof(T)); // [sw] scale
     float* sh = sc + sw;                                                    // [sw] shift
-    float* red = sh + sw;                                                   // [4 waves][4 groups][2], then the group table
+    float* red = sh + sw;                                                   // [NWV waves][4 groups][2], then the group table
     const int n = blockIdx.y;
     const int cbase = blockIdx.x * sw;
     const int cps = sw / 8;
     const int total = p.HW * cps;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < total; i += 256) {
+    for (int i = tid; i < total; i += NT) {
         const int pix = i / cps, cc = i - pix * cps;
         const T* src = gn_src<T>(p, n, pix, cbase + cc * 8);
         if (sizeof(T) == 2) {
@@ -251,14 +252,14 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GnP p, int sw) {
         }
     }
     // group of every channel of the set (sw small divisions instead of one per element)
-    unsigned char* gidx = reinterpret_cast<unsigned char*>(red + 64);
-    for (int c = tid; c < sw; c += 256) gidx[c] = (unsigned char)(c / p.Cg);
+    unsigned char* gidx = reinterpret_cast<unsigned char*>(red + NWV * 8);
+    for (int c = tid; c < sw; c += NT) gidx[c] = (unsigned char)(c / p.Cg);
     __syncthreads();
     const int ng = sw / p.Cg; // <= 4 for every SD channel count (asserted on the host)
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, shf[4];
 #pragma unroll
     for (int gi = 0; gi < 4; ++gi) shf[gi] = gi < ng ? (float)slab[gi * p.Cg] : 0.f; // pilot shift: first element of the group
-    for (int i = tid; i < total; i += 256) {
+    for (int i = tid; i < total; i += NT) {
         const int pix = i / cps, cc = i - pix * cps;
         float v[8];
         Chunk8<T>::load(slab + (size_t)pix * sw + cc * 8, v);
@@ -287,11 +288,11 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GnP p, int sw) {
     }
     __syncthreads();
     const float inv_cnt = 1.0f / ((float)p.HW * (float)p.Cg);
-    for (int c = tid; c < sw; c += 256) {
+    for (int c = tid; c < sw; c += NT) {
         const int gi = gidx[c];
         float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NWV; ++w) {
             a += red[(w * 4 + gi) * 2 + 0];
             b += red[(w * 4 + gi) * 2 + 1];
         }
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GnP p, int sw) {
     }
     __syncthreads();
     T* yout = reinterpret_cast<T*>(p.y) + (size_t)n * p.HW * p.C + cbase;
-    for (int i = tid; i < total; i += 256) {
+    for (int i = tid; i < total; i += NT) {
         const int pix = i / cps, cc = i - pix * cps;
         float v[8];
         Chunk8<T>::load(slab + (size_t)pix * sw + cc * 8, v);
@@ -323,27 +324,35 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GnP p, int sw) {
 
 static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 
-// single-launch path eligibility (also what sdod_group_norm_launches reports)
+// single-launch path eligibility (also what sdod_group_norm_launches reports).  Up to 256 pixels a 256-thread workgroup
+// per (image, channel set) is enough; up to 1024 pixels (the 32x32 level: slab of 80 KB) it takes 1024 threads to keep
+// enough loads in flight for the few workgroups there are (c = 640: 32 of them).
+static size_t gn_small_smem(int hw, int sw, size_t elem) { return (size_t)hw * sw * elem + ((size_t)2 * sw + 128) * sizeof(float) + (size_t)sw; }
 static bool gn_small_fits(int hw, int c, int cg, size_t elem) {
     const int sw = cg / gcd_i(cg, 8) * 8; // lcm(Cg, 8)
     if (c % sw != 0) return false;
-    const size_t smem = (size_t)hw * sw * elem + ((size_t)2 * sw + 64) * sizeof(float) + (size_t)sw;
-    return hw <= 256 && sw / cg <= 4 && smem <= 96 * 1024;
+    return hw <= 1024 && sw / cg <= 4 && gn_small_smem(hw, sw, elem) <= 96 * 1024;
+}
+
+template <typename T, int NT>
+void gn_small_launch(GnP& p, int sw, size_t smem, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SDOD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<T, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           96 * 1024 + 4096));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gn_small_kernel<T, NT>), dim3(p.C / sw, p.N), dim3(NT), smem, st, p, sw);
+    SDOD_HIP_CHECK(hipGetLastError());
 }
 
 template <typename T>
 bool gn_try_small(GnP& p, hipStream_t st) {
     const int sw = p.Cg / gcd_i(p.Cg, 8) * 8; // lcm(Cg, 8)
     if (!gn_small_fits(p.HW, p.C, p.Cg, sizeof(T))) return false;
-    const size_t smem = (size_t)p.HW * sw * sizeof(T) + ((size_t)2 * sw + 64) * sizeof(float) + (size_t)sw;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SDOD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           96 * 1024 + 4096));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gn_small_kernel<T>), dim3(p.C / sw, p.N), dim3(256), smem, st, p, sw);
-    SDOD_HIP_CHECK(hipGetLastError());
+    const size_t smem = gn_small_smem(p.HW, sw, sizeof(T));
+    if (p.HW > 256) gn_small_launch<T, 1024>(p, sw, smem, st);
+    else gn_small_launch<T, 256>(p, sw, smem, st);
     return true;
 }
 
