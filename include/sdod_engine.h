@@ -58,9 +58,15 @@ typedef struct sdod_model_config {
     int text_layers;     /* 12 */
     int text_heads;      /* 12 */
     int vae_channels;    /* 128 */
+    int linear_proj;     /* 0: transformer proj_in / proj_out are 1x1 convs [C,C,1,1] (SD1.x); 1: Linear [C,C] (SD2.x
+                          * `use_linear_in_transformer`) -- same arithmetic, different checkpoint shapes */
 } sdod_model_config;
 
 SDOD_API void sdod_model_config_sd14(sdod_model_config* cfg);
+/* SD v2.1-768 UNet / VAE shapes (BASELINE config 5): 96x96 latent, context 1024, 64-wide heads (5/10/20/20 of them),
+ * linear transformer projections.  Its text encoder (OpenCLIP ViT-H) is NOT one of this library's graphs: feed the
+ * UNET graph's context input directly. */
+SDOD_API void sdod_model_config_sd21(sdod_model_config* cfg);
 
 SDOD_API int sdod_graph_create(void** graph, int kind, const sdod_model_config* cfg, int batch);
 SDOD_API int sdod_graph_destroy(void* graph);

@@ -36,7 +36,9 @@ extern "C" {
 #endif
 
 enum sdod_act { SDOD_ACT_NONE = 0, SDOD_ACT_SILU = 1, SDOD_ACT_GELU = 2, SDOD_ACT_QUICK_GELU = 3 };
-enum sdod_dtype { SDOD_F16 = 0, SDOD_F32 = 1 };
+/* SDOD_U8Q (graph parameters only): per-tensor affine uint8, the reference's QNN weight format (`quantize=8`, todlc.py:108;
+ * qnn_context.cpp:1018-1033): payload = {float scale; int32 offset (<= 0); uint8 q[numel]}, real = (q + offset) * scale */
+enum sdod_dtype { SDOD_F16 = 0, SDOD_F32 = 1, SDOD_U8Q = 2 };
 enum sdod_a_mode { SDOD_A_ROWS = 0, SDOD_A_CONV3X3 = 1 /* NHWC gather: 3x3 pad 1 or 1x1 */ };
 
 /* out[M][N] = act(alpha * A[M][K] . W[N][K]^T + bias + row_bias) + residual        (fp16 in/out, fp32 acc)

@@ -30,7 +30,9 @@ def guided_eps(unet, x, t, ctx_uc, ctx_c, scale):
 
 
 @torch.no_grad()
-def plms_sample(unet, ctx_uc, ctx_c, x_T, steps=20, scale=7.5, trace=None):
+def plms_sample(unet, ctx_uc, ctx_c, x_T, steps=20, scale=7.5, trace=None, parameterization='eps'):
+    """parameterization='v' (SD 2.1-768): the guided model output is v and eps = sqrt(abar_t) v + sqrt(1 - abar_t) x
+    (public ldm v2 `predict_eps_from_z_and_v`, applied in PLMSSampler.get_model_output)"""
     ac = torch.from_numpy(_alphas_cumprod()).to(torch.float32)
     c = 1000 // steps
     ddim_timesteps = np.asarray(list(range(0, 1000, c))) + 1
@@ -41,7 +43,11 @@ def plms_sample(unet, ctx_uc, ctx_c, x_T, steps=20, scale=7.5, trace=None):
 
     def model_out(x, t):
         e_u, e_c = guided_eps(unet, x, t, ctx_uc, ctx_c, scale)
-        return e_u + scale * (e_c - e_u)
+        out = e_u + scale * (e_c - e_u)
+        if parameterization == 'v':
+            a = ac[t].reshape(-1, 1, 1, 1)
+            out = a.sqrt() * out + (1. - a).sqrt() * x
+        return out
 
     def x_prev_of(x, e_t, index):
         a_t = torch.full((b, 1, 1, 1), float(alphas[index]))

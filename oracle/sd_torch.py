@@ -109,22 +109,33 @@ class BasicTransformerBlock(nn.Module):
 
 
 class SpatialTransformer(nn.Module):
-    def __init__(self, ch, heads, d_head, context_dim):
+    """use_linear=False: SD1.x (1x1 conv projections); True: SD2.x `use_linear_in_transformer` (Linear on the token view)"""
+
+    def __init__(self, ch, heads, d_head, context_dim, use_linear=False):
         super().__init__()
+        self.use_linear = use_linear
         self.norm = nn.GroupNorm(32, ch, eps=1e-6, affine=True)
-        self.proj_in = nn.Conv2d(ch, heads * d_head, 1)
+        self.proj_in = nn.Linear(ch, heads * d_head) if use_linear else nn.Conv2d(ch, heads * d_head, 1)
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(heads * d_head, heads, d_head, context_dim)])
-        self.proj_out = nn.Conv2d(heads * d_head, ch, 1)
+        self.proj_out = nn.Linear(heads * d_head, ch) if use_linear else nn.Conv2d(heads * d_head, ch, 1)
 
     def forward(self, x, emb=None, context=None):
         b, c, h, w = x.shape
         x_in = x
-        x = self.proj_in(self.norm(x))
+        x = self.norm(x)
+        if not self.use_linear:
+            x = self.proj_in(x)
         x = x.permute(0, 2, 3, 1).reshape(b, h * w, -1)
+        if self.use_linear:
+            x = self.proj_in(x)
         for blk in self.transformer_blocks:
             x = blk(x, context)
+        if self.use_linear:
+            x = self.proj_out(x)
         x = x.reshape(b, h, w, -1).permute(0, 3, 1, 2)
-        return self.proj_out(x) + x_in
+        if not self.use_linear:
+            x = self.proj_out(x)
+        return x + x_in
 
 
 class Downsample(nn.Module):
@@ -157,8 +168,11 @@ class UNetModel(nn.Module):
     8 heads, transformer depth 1, context 768)."""
 
     def __init__(self, in_ch=4, out_ch=4, model_ch=320, mult=(1, 2, 4, 4), num_res=2, attn_ds=(1, 2, 4), heads=8,
-                 context_dim=768):
+                 context_dim=768, head_dim=None, use_linear=False):
+        """SD2.x (public ldm v2 config): head_dim=64 (heads = ch // 64), context_dim=1024, use_linear=True"""
         super().__init__()
+        st = lambda ch: SpatialTransformer(ch, ch // head_dim if head_dim else heads, head_dim if head_dim else ch // heads,
+                                           context_dim, use_linear)
         emb_ch = model_ch * 4
         self.model_ch = model_ch
         self.time_embed = nn.Sequential(nn.Linear(model_ch, emb_ch), nn.SiLU(), nn.Linear(emb_ch, emb_ch))
@@ -170,22 +184,21 @@ class UNetModel(nn.Module):
                 layers = [ResBlock(ch, m * model_ch, emb_ch)]
                 ch = m * model_ch
                 if ds in attn_ds:
-                    layers.append(SpatialTransformer(ch, heads, ch // heads, context_dim))
+                    layers.append(st(ch))
                 self.input_blocks.append(TimestepSeq(*layers))
                 chans.append(ch)
             if level != len(mult) - 1:
                 self.input_blocks.append(TimestepSeq(Downsample(ch)))
                 chans.append(ch)
                 ds *= 2
-        self.middle_block = TimestepSeq(ResBlock(ch, ch, emb_ch), SpatialTransformer(ch, heads, ch // heads, context_dim),
-                                        ResBlock(ch, ch, emb_ch))
+        self.middle_block = TimestepSeq(ResBlock(ch, ch, emb_ch), st(ch), ResBlock(ch, ch, emb_ch))
         self.output_blocks = nn.ModuleList()
         for level, m in list(enumerate(mult))[::-1]:
             for i in range(num_res + 1):
                 layers = [ResBlock(ch + chans.pop(), m * model_ch, emb_ch)]
                 ch = m * model_ch
                 if ds in attn_ds:
-                    layers.append(SpatialTransformer(ch, heads, ch // heads, context_dim))
+                    layers.append(st(ch))
                 if level and i == num_res:
                     layers.append(Upsample(ch))
                     ds //= 2

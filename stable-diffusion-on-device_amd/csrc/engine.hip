@@ -219,11 +219,29 @@ void Graph::set_param(const std::string& name, const void* data, int dtype, cons
     auto it = pindex_.find(name);
     SDOD_REQUIRE(it != pindex_.end(), "unknown parameter '" + name + "'");
     SDOD_REQUIRE(data != nullptr, "null data for '" + name + "'");
-    SDOD_REQUIRE(dtype == SDOD_F32 || dtype == SDOD_F16, "dtype must be SDOD_F32 or SDOD_F16");
+    SDOD_REQUIRE(dtype == SDOD_F32 || dtype == SDOD_F16 || dtype == SDOD_U8Q, "dtype must be SDOD_F32, SDOD_F16 or SDOD_U8Q");
     Param& p = params_[it->second];
     int64_t want = 1, got = 1;
     for (auto d : p.shape) want *= d;
     for (int i = 0; i < ndim; ++i) got *= shape[i];
+    // int8-weight checkpoints (BASELINE config 5, "mirrors the QNN quant path"): dequantised here, once, with the reference's
+    // own arithmetic -- real = (q + offset) * scale evaluated in double, then rounded to float (qnn_context.cpp:1018-1033);
+    // the kernels then run on the fp16 image of those values, exactly as they do for an fp16 checkpoint
+    std::vector<float> deq;
+    if (dtype == SDOD_U8Q) {
+        float scale;
+        int32_t offset;
+        std::memcpy(&scale, data, 4);
+        std::memcpy(&offset, static_cast<const char*>(data) + 4, 4);
+        const uint8_t* q = static_cast<const uint8_t*>(data) + 8;
+        deq.resize((size_t)got);
+        float* dst = deq.data();
+        parallel_for(got, [&](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i) dst[i] = (float)((double)((int32_t)q[i] + offset) * (double)scale);
+        });
+        data = deq.data();
+        dtype = SDOD_F32;
+    }
     bool same = (int)p.shape.size() == ndim;
     for (int i = 0; same && i < ndim; ++i) same = p.shape[i] == shape[i];
     // a [Cout][Cin] matrix is accepted for a 1x1 conv and vice versa (SD2.x stores proj_in/out as Linear)
@@ -792,6 +810,17 @@ extern "C" void sdod_model_config_sd14(sdod_model_config* cfg) {
     cfg->text_layers = 12;
     cfg->text_heads = 12;
     cfg->vae_channels = 128;
+    cfg->linear_proj = 0;
+}
+
+extern "C" void sdod_model_config_sd21(sdod_model_config* cfg) {
+    if (!cfg) return;
+    sdod_model_config_sd14(cfg);
+    cfg->latent_h = cfg->latent_w = 96;
+    cfg->context_dim = 1024;
+    cfg->num_heads = 0;
+    cfg->head_dim = 64;
+    cfg->linear_proj = 1;
 }
 
 extern "C" int sdod_graph_create(void** graph, int kind, const sdod_model_config* cfg, int batch) {

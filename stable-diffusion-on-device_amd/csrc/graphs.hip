@@ -81,7 +81,9 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     const int rows = x.rows(), L = x.h * x.w, B = x.n;
     const std::string tb = pfx + ".transformer_blocks.0";
     const int nw = P(pfx + ".norm.weight", {C}, PK_VEC), nb = P(pfx + ".norm.bias", {C}, PK_VEC);
-    const int piw = P(pfx + ".proj_in.weight", {C, C, 1, 1}, PK_CONV1), pib = P(pfx + ".proj_in.bias", {C}, PK_VEC);
+    const bool lin = cfg_.linear_proj != 0; // SD2.x stores these as Linear [C, C]; the arithmetic is the same
+    const int piw = lin ? P(pfx + ".proj_in.weight", {C, C}, PK_LINEAR) : P(pfx + ".proj_in.weight", {C, C, 1, 1}, PK_CONV1);
+    const int pib = P(pfx + ".proj_in.bias", {C}, PK_VEC);
     const int l1w = P(tb + ".norm1.weight", {C}, PK_VEC), l1b = P(tb + ".norm1.bias", {C}, PK_VEC);
     const std::string gq = tb + ".attn1.qkv";
     P(tb + ".attn1.to_q.weight", {C, C}, PK_LINEAR, gq);
@@ -100,7 +102,8 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     const int l3w = P(tb + ".norm3.weight", {C}, PK_VEC), l3b = P(tb + ".norm3.bias", {C}, PK_VEC);
     const int f1w = P(tb + ".ff.net.0.proj.weight", {8 * C, C}, PK_LINEAR_GEGLU), f1b = P(tb + ".ff.net.0.proj.bias", {8 * C}, PK_VEC_GEGLU);
     const int f2w = P(tb + ".ff.net.2.weight", {C, 4 * C}, PK_LINEAR), f2b = P(tb + ".ff.net.2.bias", {C}, PK_VEC);
-    const int pow_ = P(pfx + ".proj_out.weight", {C, C, 1, 1}, PK_CONV1), pob = P(pfx + ".proj_out.bias", {C}, PK_VEC);
+    const int pow_ = lin ? P(pfx + ".proj_out.weight", {C, C}, PK_LINEAR) : P(pfx + ".proj_out.weight", {C, C, 1, 1}, PK_CONV1);
+    const int pob = P(pfx + ".proj_out.bias", {C}, PK_VEC);
     if (mode_ == DECLARE) return act(x.n, x.h, x.w, C);
 
     Act g = group_norm(x, nullptr, nw, nb, 1e-6f, false);

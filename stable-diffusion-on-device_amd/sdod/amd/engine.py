@@ -16,11 +16,11 @@ class ModelConfig(ctypes.Structure):
     """mirror of `struct sdod_model_config`"""
     _fields_ = [(n, ctypes.c_int) for n in (
         'latent_channels', 'latent_h', 'latent_w', 'model_channels', 'context_dim', 'context_len', 'num_heads',
-        'head_dim', 'vocab_size', 'text_layers', 'text_heads', 'vae_channels')]
+        'head_dim', 'vocab_size', 'text_layers', 'text_heads', 'vae_channels', 'linear_proj')]
 
 
 ENGINE_SYMBOLS = [
-    'sdod_model_config_sd14', 'sdod_graph_create', 'sdod_graph_destroy', 'sdod_graph_num_params', 'sdod_graph_param_info',
+    'sdod_model_config_sd14', 'sdod_model_config_sd21', 'sdod_graph_create', 'sdod_graph_destroy', 'sdod_graph_num_params', 'sdod_graph_param_info',
     'sdod_graph_set_param', 'sdod_graph_load_file', 'sdod_graph_finalize', 'sdod_graph_io', 'sdod_graph_execute',
     'sdod_graph_stats', 'sdod_graph_num_ops', 'sdod_graph_op_info', 'sdod_graph_op_detail', 'sdod_graph_profile',
 ]
@@ -32,6 +32,8 @@ def _engine():
         P, I = ctypes.c_void_p, ctypes.c_int
         lib.sdod_model_config_sd14.argtypes = [ctypes.POINTER(ModelConfig)]
         lib.sdod_model_config_sd14.restype = None
+        lib.sdod_model_config_sd21.argtypes = [ctypes.POINTER(ModelConfig)]
+        lib.sdod_model_config_sd21.restype = None
         lib.sdod_graph_create.argtypes = [ctypes.POINTER(P), I, ctypes.POINTER(ModelConfig), I]
         lib.sdod_graph_destroy.argtypes = [P]
         lib.sdod_graph_num_params.argtypes = [P]
@@ -54,6 +56,14 @@ def _engine():
 def sd14_config(latent_h=64, latent_w=64):
     cfg = ModelConfig()
     _engine().sdod_model_config_sd14(ctypes.byref(cfg))
+    cfg.latent_h, cfg.latent_w = latent_h, latent_w
+    return cfg
+
+
+def sd21_config(latent_h=96, latent_w=96):
+    """SD v2.1-768 UNet / VAE shapes (BASELINE config 5); the text encoder (OpenCLIP ViT-H) is not a graph of this library"""
+    cfg = ModelConfig()
+    _engine().sdod_model_config_sd21(ctypes.byref(cfg))
     cfg.latent_h, cfg.latent_w = latent_h, latent_w
     return cfg
 
@@ -103,6 +113,12 @@ class Graph:
         return out
 
     def set_param(self, name, tensor):
+        if hasattr(tensor, 'payload'):     # weights.QuantU8: the library dequantises with the reference's arithmetic
+            buf = tensor.payload()
+            shape = (ctypes.c_int64 * max(len(tensor.shape), 1))(*tensor.shape)
+            check(self._lib.sdod_graph_set_param(self._h, name.encode(), ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p), 2, shape,
+                                                 len(tensor.shape)))
+            return
         t = tensor.detach().cpu().contiguous()
         if t.dtype not in (torch.float32, torch.float16):
             t = t.float()

@@ -16,17 +16,23 @@ from .samplers import PLMS_ORDERS, PlmsSchedule
 
 class Txt2Img:
     def __init__(self, state_dicts=None, models_dir=None, images_per_gpu=1, latent_hw=64, device='cuda:0', use_hip_graph=True,
-                 tokenizer=None, with_text_encoder=True):
-        """state_dicts: {'unet': sd, 'temb': sd, 'text': sd, 'vae': sd} in ldm/HF naming (canonical layouts), or models_dir
-        with the .sdodw containers libsdod_setup uses."""
+                 tokenizer=None, with_text_encoder=True, model='sd14', with_vae=True):
+        """state_dicts: {'unet': sd, 'temb': sd, 'text': sd, 'vae': sd} in ldm/HF naming (canonical layouts; values may be
+        weights.QuantU8 for an int8-weight checkpoint), or models_dir with the .sdodw containers libsdod_setup uses.
+        model='sd21': SD v2.1-768 UNet shapes + v-prediction (BASELINE config 5); its OpenCLIP text encoder is not part of
+        this library, so the conditioning [2, 77, 1024] is supplied by the caller (with_text_encoder is ignored)."""
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.n = images_per_gpu
-        self.cfg = E.sd14_config(latent_hw, latent_hw)
+        self.model = model
+        self.v_prediction = model == 'sd21'
+        if model == 'sd21':
+            with_text_encoder = False
+        self.cfg = E.sd21_config(latent_hw, latent_hw) if model == 'sd21' else E.sd14_config(latent_hw, latent_hw)
         self.use_hip_graph = use_hip_graph
         self.tokenizer = tokenizer
         self.unet = E.UNet(self.cfg, 2 * self.n, device)
-        self.vae = E.VaeDecoder(self.cfg, 1, device)
+        self.vae = E.VaeDecoder(self.cfg, 1, device) if with_vae else None
         self.text = E.TextEncoder(self.cfg, 2, device) if with_text_encoder else None
         self._temb_graphs = {}
         self._sd = state_dicts
@@ -79,14 +85,18 @@ class Txt2Img:
         self.unet.ctx[n:].copy_(ctx2[1:2].expand(n, -1, -1))
         self._ctx_fresh = True     # the next UNet execute must redo the cross-attention K/V projections
 
-    def _eps(self, x, temb_row, guidance, mode):
-        """x: fp32 [n,4,H,W]; returns guided eps fp32 [n,4,H,W].  Batch rows: [uncond x n ; cond x n] (ldm order)."""
+    def _eps(self, x, temb_row, guidance, mode, v_coef=None):
+        """x: fp32 [n,4,H,W]; returns guided eps fp32 [n,4,H,W].  Batch rows: [uncond x n ; cond x n] (ldm order).
+        v_coef = (sqrt(abar_t), sqrt(1 - abar_t)) for a v-prediction model: the guided output is v, eps follows from it."""
         n = self.n
         self.unet.x[:n].copy_(x); self.unet.x[n:].copy_(x)
         self.unet.temb.copy_(temb_row.unsqueeze(0).expand(2 * n, -1))
         self.unet.execute(self.use_hip_graph, static_unchanged=not self._ctx_fresh)
         self._ctx_fresh = False
-        return ops.cfg_combine(self.unet.eps, guidance, uncond_first=True, mode=mode)
+        out = ops.cfg_combine(self.unet.eps, guidance, uncond_first=True, mode=mode)
+        if v_coef is not None:
+            out = ops.lincomb4([out, x], [v_coef[0], v_coef[1]], 1.0)
+        return out
 
     # ------------------------------------------------------------------ samplers
     def sample_plms(self, ctx2, x_T, steps=20, guidance=7.5, trace=None):
@@ -97,12 +107,13 @@ class Txt2Img:
         old = []
         for i, step in enumerate(sch.time_range):
             index = sch.steps - i - 1
-            e_t = self._eps(x, temb[index], guidance, mode=1)
+            vc = sch.v_to_eps_coef(index) if self.v_prediction else None
+            e_t = self._eps(x, temb[index], guidance, mode=1, v_coef=vc)
             if len(old) == 0:
                 x_pred = x.clone()
                 ops.ddim_step(x_pred, e_t, **sch.coef(index))
                 nxt = max(index - 1, 0)
-                e_next = self._eps(x_pred, temb[nxt], guidance, mode=1)
+                e_next = self._eps(x_pred, temb[nxt], guidance, mode=1, v_coef=sch.v_to_eps_coef(nxt) if self.v_prediction else None)
                 e_prime = ops.lincomb4([e_t, e_next], [1.0, 1.0], 2.0)
             else:
                 k = min(len(old), 3)

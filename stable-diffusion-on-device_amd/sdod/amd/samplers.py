@@ -23,6 +23,12 @@ class PlmsSchedule:
         self.sqrt_one_minus_alphas = np.sqrt(np.float32(1.0) - self.alphas).astype(np.float32)
         self.steps = len(self.timesteps)
         self.time_range = np.flip(self.timesteps)                           # descending: 951, 901, ..., 1
+        # v-prediction models (SD 2.1-768): eps = sqrt(abar_t) v + sqrt(1 - abar_t) x  (ldm predict_eps_from_z_and_v)
+        self.sqrt_alphas = np.sqrt(self.alphas).astype(np.float32)
+
+    def v_to_eps_coef(self, index):
+        """(coefficient of v, coefficient of x) at ddim index `index`"""
+        return float(self.sqrt_alphas[index]), float(self.sqrt_one_minus_alphas[index])
 
     def coef(self, index):
         """fp32 scalars of get_x_prev_and_pred_x0 at ddim index `index` (sigma_t = 0)"""

@@ -9,6 +9,41 @@ import torch
 MAGIC = b'SDODW001'
 
 
+class QuantU8:
+    """per-tensor affine uint8 weight, the reference's QNN weight format (`quantize=8`, todlc.py:108): real = (q + offset)
+    * scale with q unsigned and offset <= 0 (qnn_context.cpp:1018-1033)"""
+
+    def __init__(self, q, scale, offset):
+        assert q.dtype == torch.uint8
+        self.q, self.scale, self.offset = q.contiguous(), float(scale), int(offset)
+
+    @property
+    def shape(self):
+        return self.q.shape
+
+    def dequantize(self):
+        """the reference's arithmetic: (q + offset) * scale in double, rounded to float"""
+        return ((self.q.to(torch.float64) + self.offset) * float(np.float32(self.scale))).to(torch.float32)
+
+    def payload(self):
+        return struct.pack('<fi', self.scale, self.offset) + self.q.numpy().tobytes()
+
+
+def quantize_u8(t):
+    """min/max affine quantisation of one tensor to uint8 (what a QNN converter run with 8-bit weights produces)"""
+    t = t.detach().float()
+    lo, hi = min(float(t.min()), 0.0), max(float(t.max()), 0.0)          # the range always contains 0 (offset <= 0)
+    scale = float(np.float32((hi - lo) / 255.0)) if hi > lo else 1.0
+    offset = int(round(lo / scale))
+    q = torch.clamp(torch.round(t / scale) - offset, 0, 255).to(torch.uint8)
+    return QuantU8(q, scale, offset)
+
+
+def quantize_state_dict(sd, min_ndim=2):
+    """conv / linear weights (ndim >= 2, embeddings included) -> QuantU8; biases and norm parameters stay as they are"""
+    return {k: (quantize_u8(v) if v.dim() >= min_ndim else v) for k, v in sd.items()}
+
+
 def save(path, tensors):
     """tensors: mapping name -> torch tensor (fp32 or fp16, canonical PyTorch layout).  Layout of the file:
     MAGIC, u64 count, per tensor {u32 name_len, name, u32 dtype (0 f16, 1 f32), u32 ndim, u64 dims[ndim], u64 offset,
@@ -16,20 +51,22 @@ def save(path, tensors):
     items = []
     header = 16
     for name, t in tensors.items():
-        t = t.detach().cpu().contiguous()
-        if t.dtype not in (torch.float16, torch.float32):
-            t = t.float()
+        if not isinstance(t, QuantU8):
+            t = t.detach().cpu().contiguous()
+            if t.dtype not in (torch.float16, torch.float32):
+                t = t.float()
         items.append((name.encode(), t))
-        header += 4 + len(name.encode()) + 8 + 8 * t.dim() + 16
+        header += 4 + len(name.encode()) + 8 + 8 * len(t.shape) + 16
     pos = (header + 63) // 64 * 64
     with open(path, 'wb') as f:
         f.write(MAGIC)
         f.write(struct.pack('<Q', len(items)))
         offsets = []
         for nb, t in items:
-            nbytes = t.numel() * t.element_size()
+            quant = isinstance(t, QuantU8)
+            nbytes = 8 + t.q.numel() if quant else t.numel() * t.element_size()
             f.write(struct.pack('<I', len(nb))); f.write(nb)
-            f.write(struct.pack('<II', 1 if t.dtype == torch.float32 else 0, t.dim()))
+            f.write(struct.pack('<II', 2 if quant else (1 if t.dtype == torch.float32 else 0), len(t.shape)))
             for d in t.shape:
                 f.write(struct.pack('<Q', d))
             f.write(struct.pack('<QQ', pos, nbytes))
@@ -37,11 +74,11 @@ def save(path, tensors):
             pos = (pos + nbytes + 63) // 64 * 64
         for (nb, t), off in zip(items, offsets):
             f.seek(off)
-            f.write(t.numpy().tobytes())
+            f.write(t.payload() if isinstance(t, QuantU8) else t.numpy().tobytes())
 
 
 def load(path):
-    """Inverse of save(); returns {name: tensor}."""
+    """Inverse of save(); returns {name: tensor or QuantU8}."""
     out = {}
     with open(path, 'rb') as f:
         data = f.read()
@@ -54,6 +91,11 @@ def load(path):
         dt, nd = struct.unpack_from('<II', data, pos); pos += 8
         dims = struct.unpack_from('<' + 'Q' * nd, data, pos); pos += 8 * nd
         off, nb = struct.unpack_from('<QQ', data, pos); pos += 16
+        if dt == 2:
+            scale, offset = struct.unpack_from('<fi', data, off)
+            q = np.frombuffer(data, dtype=np.uint8, count=nb - 8, offset=off + 8)
+            out[name] = QuantU8(torch.from_numpy(q.copy()).reshape(dims), scale, offset)
+            continue
         arr = np.frombuffer(data, dtype=np.float32 if dt == 1 else np.float16, count=nb // (4 if dt == 1 else 2), offset=off)
         out[name] = torch.from_numpy(arr.copy()).reshape(dims)
     return out

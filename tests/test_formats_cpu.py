@@ -202,3 +202,51 @@ def test_latency_tables_by_launch_and_by_op_type():
     assert A.op_type('gemm_t3', 'rows M1 N1 K64 x1') == 'Linear / MatMul' and A.op_type('gemm_t8', 'conv1 ...') == 'Conv 1x1'
     text = A.format_table(by_type, ['Op.', 'Latency (us)', '% Latency', 'Launches'])
     assert 'GroupNorm(+SiLU)' in text and 'Launches' in text
+
+
+# ------------------------------------------------------------------ config 5: uint8 affine weights (QNN format) + SD 2.1 shapes
+def test_u8_weight_format_matches_reference_dequant_semantics(tmp_path, oracle_lib):
+    """weights.QuantU8 = the reference's QNN weight encoding real = (q + offset) * scale, q unsigned, offset <= 0
+    (qnn_context.cpp:1018-1033); its dequantisation must equal the C oracle of that function bit for bit"""
+    import ctypes
+    from sdod.amd import weights as Wt
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(64, 96, generator=g) * 0.05 + 0.01
+    q = Wt.quantize_u8(w)
+    assert q.q.dtype == torch.uint8 and q.offset <= 0 and q.scale > 0 and tuple(q.shape) == (64, 96)
+    deq = q.dequantize()
+    assert float((deq - w).abs().max()) <= 0.5001 * q.scale                          # round-to-nearest on a 255-step grid
+    assert int(q.q.min()) == 0 and int(q.q.max()) == 255                             # the min/max range is used fully
+    ref = np.zeros(w.numel(), np.float32)
+    raw = np.ascontiguousarray(q.q.numpy().reshape(-1))
+    oracle_lib.oracle_dequant_u8.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_uint, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_float]
+    oracle_lib.oracle_dequant_u8(ref.ctypes.data, raw.ctypes.data, q.offset, q.scale, raw.size, 0, 0, 1.0)
+    assert np.array_equal(deq.numpy().reshape(-1), ref)
+    zero = Wt.quantize_u8(torch.zeros(4, 4))                                           # degenerate range
+    assert torch.equal(zero.dequantize(), torch.zeros(4, 4))
+    pos = Wt.quantize_u8(torch.rand(8, 8, generator=g) + 1.0)                          # all-positive tensor: 0 stays representable
+    assert pos.offset == 0
+    sd = Wt.quantize_state_dict({'a.weight': w, 'a.bias': torch.randn(64, generator=g), 'n.weight': torch.ones(64)})
+    assert isinstance(sd['a.weight'], Wt.QuantU8) and not isinstance(sd['a.bias'], Wt.QuantU8)
+    p = tmp_path / 'q.sdodw'
+    Wt.save(str(p), sd)
+    back = Wt.load(str(p))
+    assert isinstance(back['a.weight'], Wt.QuantU8) and torch.equal(back['a.weight'].q, q.q)
+    assert back['a.weight'].offset == q.offset and np.float32(back['a.weight'].scale) == np.float32(q.scale)
+    assert torch.equal(back['a.bias'], sd['a.bias'])
+    assert os.path.getsize(p) < w.numel() * 2                                          # 1 byte per weight on disk
+
+
+def test_sd21_unet_parameter_table_matches_public_architecture():
+    """SD v2.1 UNet (config 5): 64-wide heads, context 1024, Linear transformer projections -> 865,910,724 parameters"""
+    from oracle import sd_torch as S
+    from sdod.amd import engine as E
+    cfg = E.sd21_config()
+    assert (cfg.latent_h, cfg.context_dim, cfg.num_heads, cfg.head_dim, cfg.linear_proj) == (96, 1024, 0, 64, 1)
+    table = dict(E.UNet(cfg, 2).param_table() + E.Temb(cfg, 1).param_table())
+    with torch.device('meta'):
+        ref = S.UNetModel(context_dim=1024, head_dim=64, use_linear=True)
+    want = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    assert table == want
+    assert sum(int(np.prod(s)) for s in table.values()) == 865_910_724

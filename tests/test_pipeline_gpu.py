@@ -118,3 +118,67 @@ def test_config4_dpm_50_steps_two_images_per_gpu(rig, oracle_lib):
         assert r <= 2e-2, r
     img = pipe.decode(z, mode=0)
     assert img.shape == (2, 128, 128, 3) and img.dtype == torch.uint8
+
+
+# ------------------------------------------------------------------ BASELINE config 5: SD v2.1 shapes, int8 weights, PLMS
+@pytest.fixture(scope='module')
+def rig21():
+    """SD v2.1 UNet (64-wide heads, context 1024, Linear transformer projections) with every conv / linear weight stored
+    as per-tensor affine uint8 (the reference's QNN weight format); the oracle computes in fp32 on the SAME dequantised
+    values.  Latent 24x24 keeps the CPU side short; the 96x96 evaluation is test_config5_unet_step_at_768px."""
+    from oracle import sd_torch as S
+    from sdod.amd import engine as E, weights as Wt
+    cfg = E.sd21_config(24, 24)
+    tables = {'unet': E.UNet(cfg, 2).param_table(), 'temb': E.Temb(cfg, 1).param_table()}
+    sds = {k: Wt.quantize_state_dict(Wt.synthetic_state_dict(t, seed=2100 + i)) for i, (k, t) in enumerate(tables.items())}
+    nq = sum(isinstance(v, Wt.QuantU8) for sd in sds.values() for v in sd.values())
+    assert nq == 282                                  # every conv / linear weight of the UNET + TEMB graphs
+    with torch.device('meta'):
+        unet = S.UNetModel(context_dim=1024, head_dim=64, use_linear=True)
+    deq = {k: (v.dequantize() if isinstance(v, Wt.QuantU8) else v) for sd in sds.values() for k, v in sd.items()}
+    unet.load_state_dict(deq, assign=True)
+    return sds, unet.eval()
+
+
+def test_config5_sd21_int8_weights_plms_matches_oracle(rig21):
+    from oracle import pipeline_oracle as PO
+    from sdod.amd.pipeline import Txt2Img
+    sds, unet = rig21
+    pipe = Txt2Img(state_dicts=sds, images_per_gpu=1, latent_hw=24, model='sd21', with_vae=False)
+    g = torch.Generator().manual_seed(77)
+    ctx2 = torch.randn(2, 77, 1024, generator=g).half().cuda()           # stands in for the OpenCLIP-H output (not built)
+    x_T = torch.randn(1, 4, 24, 24, generator=g)
+    tr_gpu, tr_cpu = [], []
+    z = pipe.sample_plms(ctx2, x_T, steps=20, guidance=7.5, trace=tr_gpu)
+    c = ctx2.float().cpu()
+    z_ref = PO.plms_sample(unet, c[0:1], c[1:2], x_T, steps=20, scale=7.5, trace=tr_cpu, parameterization='v')
+    assert tr_gpu == tr_cpu
+    r = rel_l2(z.cpu(), z_ref)
+    print('config 5 (sd21 shapes, u8 weights, v-prediction PLMS) final latent rel-L2', r)
+    assert torch.isfinite(z).all() and r <= 2e-2, r
+
+
+def test_config5_unet_step_at_768px(rig21):
+    """one batch-2 UNet evaluation at the full 96x96 latent of SD v2.1-768 (L = 9216 tokens at 64-wide heads)"""
+    from sdod.amd import engine as E
+    sds, unet = rig21
+    cfg = E.sd21_config(96, 96)
+    g = E.UNet(cfg, 2)
+    g.load_state_dict(sds['unet'])
+    g.finalize()
+    te = E.Temb(cfg, 1)
+    te.load_state_dict(sds['temb'])
+    te.finalize()
+    gen = torch.Generator().manual_seed(78)
+    x = torch.randn(2, 4, 96, 96, generator=gen)
+    ctx = torch.randn(2, 77, 1024, generator=gen).half()
+    te.t.copy_(torch.tensor([601.0]))
+    te.execute()
+    g.x.copy_(x); g.ctx.copy_(ctx); g.temb.copy_(te.out.expand(2, -1))
+    g.execute(True)
+    out = g.eps.float().cpu().permute(0, 3, 1, 2)
+    with torch.no_grad():
+        ref = unet(x, torch.tensor([601.0, 601.0]), ctx.float())
+    r = rel_l2(out, ref)
+    print('config 5 UNet step @96x96 rel-L2', r, g.stats())
+    assert torch.isfinite(out).all() and r <= 1e-2, r

@@ -1,3 +1,2 @@
 export PYTHONUNBUFFERED=1
-for HW in 1024 256 1024 256; do SDOD_GN_SMALL_HW=$HW timeout -k 10 400 python bench.py --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | tail -1 > gpurun_out/bench_gn$HW.json; python -c "
-import json; d=json.load(open('gpurun_out/bench_gn$HW.json')); print('gn_small up to hw $HW:', d['value'], 'img/s', d['unet_step_ms'], 'ms/step')"; done
+timeout -k 10 300 python tools/unet_profile.py vae --top 40 > gpurun_out/vae_prof2.txt 2>&1; head -44 gpurun_out/vae_prof2.txt

@@ -14,12 +14,20 @@ ap.add_argument('kind', nargs='?', default='unet')
 ap.add_argument('--hw', type=int, default=64)
 ap.add_argument('--batch', type=int, default=2)
 ap.add_argument('--top', type=int, default=70)
+ap.add_argument('--model', default='sd14', choices=['sd14', 'sd21'], help='sd21: SD v2.1-768 UNet shapes (config 5), use --hw 96')
 a = ap.parse_args()
-cfg = E.sd14_config(a.hw, a.hw)
+cfg = (E.sd21_config if a.model == 'sd21' else E.sd14_config)(a.hw, a.hw)
 g = {'unet': E.UNet, 'vae': E.VaeDecoder, 'text': E.TextEncoder}[a.kind](cfg, a.batch if a.kind != 'vae' else 1)
 g.load_state_dict(Wt.synthetic_state_dict(g.param_table(), seed=1, dtype=torch.float16))
 g.finalize()
 g.execute()
+import time  # noqa: E402
+g.execute(True); g.execute(True); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    g.execute(True, True) if a.kind == 'unet' else g.execute(True)
+torch.cuda.synchronize()
+print(f'{a.kind} {a.model} hw{a.hw} batch {g.batch}: {(time.perf_counter() - t0) * 100:.3f} ms per hipGraph replay, {g.stats()["flops"] / 1e12:.3f} TFLOP')
 ms = g.profile(iters=5)
 tab = g.op_table(); det = g.op_details()
 rows = sorted(zip(ms, tab, det), key=lambda r: -r[0])
