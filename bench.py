@@ -196,12 +196,21 @@ def main():
         else:
             ach = d['bytes'] / (d['ms'] * 1e-3) / 1e9
             roof = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
-        # HBM bytes per launch of that kernel family from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected offline in
-        # separate passes with tools/pmc_traffic.py and committed under profiles/; null when no measurement matches)
+        # HBM bytes per launch of that kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected offline in separate
+        # passes by tools/run_profile.sh, summarised with the guide's gfx950 corrections by tools/pmc_summary.py and committed
+        # under profiles/; null when no measurement matches the dominant symbol)
         try:
-            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))['labels']
-            roof['traffic'] = round(tr[dom]['hbm_bytes_per_launch'])
-        except (OSError, ValueError, KeyError):
+            import re
+            sym = KERNEL_SYMBOLS.get(dom, dom)
+            nums = re.findall(r'\d+', sym)
+            mangled = ''.join(f'Li{n}E' for n in nums) if sym.startswith('gemm_glds_kernel') else None
+            for k in json.load(open(os.path.join(ROOT, 'profiles', 'r01_d_pmc_summary.json')))['kernels']:
+                name = k['kernel']
+                if (mangled and 'gemm_glds_kernel' in name and ('I' + mangled + 'E') in name) or (not mangled and sym in name):
+                    roof['traffic'] = k['hbm_fetch_bytes_per_launch'] + k['hbm_write_bytes_per_launch']
+                    roof['mfma_util_pmc'] = k['mfma_util']
+                    break
+        except (OSError, ValueError, KeyError, TypeError):
             pass
         roof.update(kernel=dom, kernel_symbol=KERNEL_SYMBOLS.get(dom, dom),
                     flops_per_launch=round(d['flops'] / d['launches']), algorithmic_bytes_per_launch=round(d['bytes'] / d['launches']),
