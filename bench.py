@@ -79,6 +79,8 @@ def parse():
     ap.add_argument('--images-per-gpu', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hip-graph', action='store_true')
+    ap.add_argument('--per-step-launches', action='store_true', help='drive the sampler loop from Python (one graph replay per UNet '
+                    'evaluation + small launches) instead of replaying the whole trajectory as one device graph')
     return ap.parse_args()
 
 
@@ -132,8 +134,10 @@ def main():
         else:
             ctx2 = torch.empty(2, cfg.context_len, cfg.context_dim, dtype=torch.float16, device=device)
         ctx2 = broadcast_conditioning(ctx2, 0)
-        z = pipe.sample_plms(ctx2, x_T, steps=20, guidance=7.5)
-        return pipe.decode(z, mode=1)
+        if args.per_step_launches or args.no_hip_graph:
+            z = pipe.sample_plms(ctx2, x_T, steps=20, guidance=7.5)
+            return pipe.decode(z, mode=1)
+        return pipe.generate_graphed(ctx2, x_T, steps=20, guidance=7.5, sampler='plms')
 
     def barrier():
         if dist is not None:
@@ -230,7 +234,8 @@ def main():
             'config': {'workload': 'SD v1.4 txt2img 512x512, 20-step PLMS (21 UNet evals, batch 2 = cond+uncond per image), '
                                    'CLIP encode + VAE decode + uint8, guidance 7.5',
                        'images_per_gpu': n, 'global_batch': n * world, 'parallelism': f'dp{world} (image shards, 1 RCCL broadcast)',
-                       'hip_graph': not args.no_hip_graph},
+                       'hip_graph': not args.no_hip_graph,
+                       'trajectory_graph': not (args.per_step_launches or args.no_hip_graph)},
             'unet_step_ms': round(unet_step_ms, 3),
             'roofline': roof,
             'setup_s': round(setup_s, 1),

@@ -740,9 +740,41 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
     const int n4 = (p.N + 3) / 4;
     const size_t total = (size_t)p.M * n4;
+    // fast path (every use in the graphs): whole quads, 16-byte aligned vectors -> one load per operand and one 8-byte store
+    // per thread, all issued before the first use (the per-element scalar form was a chain of dependent L2 round trips)
+    const bool vec = (p.N % 4 == 0) && (p.ldo % 4 == 0) && !p.bias_on_m && (p.residual == nullptr || p.ldr % 4 == 0) &&
+                     (p.row_bias == nullptr || p.ldrb % 4 == 0) && (((uintptr_t)p.out | (uintptr_t)p.residual | (uintptr_t)p.row_bias) & 7) == 0 &&
+                     (((uintptr_t)p.bias | (uintptr_t)p.bias2) & 15) == 0;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(idx / n4);
         const int n = (int)(idx - (size_t)m * n4) * 4;
+        if (vec) {
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 b1 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
+            const f32x4 b2 = p.bias2 ? *reinterpret_cast<const f32x4*>(p.bias2 + n) : zero4;
+            f16x4 rb = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f}, rs = rb;
+            if (p.row_bias) rb = *reinterpret_cast<const f16x4*>(p.row_bias + (size_t)(m / p.rows_per_img) * p.ldrb + n);
+            if (p.residual) rs = *reinterpret_cast<const f16x4*>(p.residual + (size_t)m * p.ldr + n);
+            f32x4 v = zero4;
+            for (int s = 0; s < p.splits; ++s) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p.partial + ((size_t)s * p.M + m) * p.N + n);
+                v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+            }
+            f16x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float f = v[r] * p.alpha;
+                if (p.bias) f += b1[r];
+                if (p.bias2) f += b2[r];
+                if (p.row_bias) f += (float)rb[r];
+                f = apply_act(f, p.act);
+                f = (float)(f16)f; // same rounding point as the un-split path
+                if (p.residual) f += (float)rs[r];
+                h[r] = (f16)f;
+            }
+            *reinterpret_cast<f16x4*>(p.out + (size_t)m * p.ldo + n) = h;
+            continue;
+        }
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         const bool full = n + 3 < p.N;
         for (int s = 0; s < p.splits; ++s) {

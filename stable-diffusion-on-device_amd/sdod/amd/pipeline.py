@@ -153,6 +153,34 @@ class Txt2Img:
         z = self.sample_plms(ctx2, x_T, steps, guidance) if sampler == 'plms' else self.sample_dpm(ctx2, x_T, steps, guidance)
         return self.decode(z, mode=1 if sampler == 'plms' else 0)
 
+    def generate_graphed(self, ctx2, x_T, steps=20, guidance=7.5, sampler='plms'):
+        """generate() with the WHOLE trajectory -- context upload, every UNet evaluation, CFG, sampler updates, VAE decode,
+        uint8 -- replayed as ONE device graph: the host enqueues a single launch per image instead of ~9 small launches per
+        step, so the GPU never waits for Python between steps (2-3 ms per image at 20 steps).  The sequence is static for a
+        given (sampler, steps, guidance, batch): it is captured once from the ordinary eager code path (so it is the same
+        kernels on the same buffers, bit for bit) and cached; ctx2 / x_T are copied into the graph's static inputs."""
+        key = (sampler, int(steps), float(guidance), tuple(x_T.shape))
+        cache = self.__dict__.setdefault('_traj', {})
+        if key not in cache:
+            s_ctx = torch.empty_like(ctx2, device=self.device)
+            s_x = torch.empty(tuple(x_T.shape), dtype=torch.float32, device=self.device)
+            s_ctx.copy_(ctx2); s_x.copy_(x_T)
+            keep = self.use_hip_graph
+            self.use_hip_graph = False          # inside a capture the UNet runs its launch list, not its own graph
+            try:
+                self.generate(s_ctx, s_x, steps, guidance, sampler)          # warm-up: kernel attributes, time embeddings, tuning
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self.generate(s_ctx, s_x, steps, guidance, sampler)
+            finally:
+                self.use_hip_graph = keep
+            cache[key] = (g, s_ctx, s_x, out)
+        g, s_ctx, s_x, out = cache[key]
+        s_ctx.copy_(ctx2); s_x.copy_(x_T)
+        g.replay()
+        return out
+
 
 def broadcast_conditioning(ctx2, src=0):
     """the one collective of the path: CLIP output [2,77,768] fp16 (236,544 B) from rank `src` to every rank over RCCL"""

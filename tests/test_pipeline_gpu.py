@@ -96,6 +96,14 @@ def test_pipeline_is_deterministic_and_sharding_invariant(rig):
     a = pipe.generate(ctx2, x, steps=4, guidance=7.5, sampler='plms')
     b = pipe.generate(ctx2, x, steps=4, guidance=7.5, sampler='plms')
     assert torch.equal(a, b)
+    # the whole trajectory replayed as ONE device graph: same kernels on the same buffers -> same bits, also for new inputs
+    c = pipe.generate_graphed(ctx2, x, steps=4, guidance=7.5, sampler='plms').clone()
+    assert torch.equal(a, c)
+    x2 = initial_latent(42, 8, (4, 16, 16))
+    d = pipe.generate_graphed(ctx2, x2, steps=4, guidance=7.5, sampler='plms').clone()
+    assert torch.equal(d, pipe.generate(ctx2, x2, steps=4, guidance=7.5, sampler='plms')) and not torch.equal(d, a)
+    e = pipe.generate_graphed(ctx2, x, steps=3, guidance=5.0, sampler='dpm').clone()
+    assert torch.equal(e, pipe.generate(ctx2, x, steps=3, guidance=5.0, sampler='dpm'))
 
 
 def test_config4_dpm_50_steps_two_images_per_gpu(rig, oracle_lib):
