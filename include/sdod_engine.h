@@ -60,12 +60,15 @@ typedef struct sdod_model_config {
     int vae_channels;    /* 128 */
     int linear_proj;     /* 0: transformer proj_in / proj_out are 1x1 convs [C,C,1,1] (SD1.x); 1: Linear [C,C] (SD2.x
                           * `use_linear_in_transformer`) -- same arithmetic, different checkpoint shapes */
+    int text_arch;       /* TEXT_ENCODER graph: 0 = CLIP ViT-L/14 as HF `CLIPTextModel` names it (quick-GELU, text_layers
+                          * blocks, last_hidden_state); 1 = OpenCLIP text tower as open_clip names it (`transformer.resblocks.N.*`,
+                          * fused `attn.in_proj_*`, erf GELU) stopped after text_layers blocks + ln_final: SD2.x conditions on the
+                          * PENULTIMATE block of ViT-H/14 (24 blocks in the checkpoint, text_layers = 23) */
 } sdod_model_config;
 
 SDOD_API void sdod_model_config_sd14(sdod_model_config* cfg);
 /* SD v2.1-768 UNet / VAE shapes (BASELINE config 5): 96x96 latent, context 1024, 64-wide heads (5/10/20/20 of them),
- * linear transformer projections.  Its text encoder (OpenCLIP ViT-H) is NOT one of this library's graphs: feed the
- * UNET graph's context input directly. */
+ * linear transformer projections, OpenCLIP ViT-H/14 text tower (width 1024, 16 heads, 23 of its 24 blocks). */
 SDOD_API void sdod_model_config_sd21(sdod_model_config* cfg);
 
 SDOD_API int sdod_graph_create(void** graph, int kind, const sdod_model_config* cfg, int batch);

@@ -376,6 +376,48 @@ class ClipTextModel(nn.Module):
         return tm.final_layer_norm(x)
 
 
+class OpenClipBlock(nn.Module):
+    """open_clip ResidualAttentionBlock (text tower): pre-LN, nn.MultiheadAttention (fused in_proj), erf-GELU MLP"""
+
+    def __init__(self, d, heads):
+        super().__init__()
+        self.ln_1 = nn.LayerNorm(d)
+        self.attn = nn.MultiheadAttention(d, heads, batch_first=True)
+        self.ln_2 = nn.LayerNorm(d)
+        self.mlp = nn.Sequential()
+        self.mlp.add_module('c_fc', nn.Linear(d, 4 * d))
+        self.mlp.add_module('gelu', nn.GELU())
+        self.mlp.add_module('c_proj', nn.Linear(4 * d, d))
+
+    def forward(self, x, mask):
+        h = self.ln_1(x)
+        x = x + self.attn(h, h, h, need_weights=False, attn_mask=mask)[0]
+        return x + self.mlp(self.ln_2(x))
+
+
+class OpenClipTextModel(nn.Module):
+    """OpenCLIP ViT-H/14 text tower as SD2.x uses it (public ldm v2 `FrozenOpenCLIPEmbedder`, layer='penultimate'): token +
+    positional embedding, the first `run_layers` of the checkpoint's 24 causal blocks, then ln_final; no text projection.
+    Keys as open_clip: token_embedding.weight, positional_embedding, transformer.resblocks.N.*, ln_final.*"""
+
+    def __init__(self, vocab=49408, d=1024, layers=24, heads=16, max_pos=77, run_layers=23):
+        super().__init__()
+        self.token_embedding = nn.Embedding(vocab, d)
+        self.positional_embedding = nn.Parameter(torch.empty(max_pos, d))
+        self.transformer = nn.Module()
+        self.transformer.resblocks = nn.ModuleList([OpenClipBlock(d, heads) for _ in range(layers)])
+        self.ln_final = nn.LayerNorm(d)
+        self.run_layers = run_layers
+
+    def forward(self, ids):
+        n = ids.shape[1]
+        x = self.token_embedding(ids) + self.positional_embedding[:n]
+        mask = torch.full((n, n), float('-inf')).triu(1)
+        for blk in self.transformer.resblocks[:self.run_layers]:
+            x = blk(x, mask)
+        return self.ln_final(x)
+
+
 # ------------------------------------------------------------------------------------ synthetic weights
 def synthetic_init_(module, seed=1234):
     """Deterministic seeded parameters: conv/linear weight ~ N(0, 1/fan_in), norm weight

@@ -811,6 +811,7 @@ extern "C" void sdod_model_config_sd14(sdod_model_config* cfg) {
     cfg->text_heads = 12;
     cfg->vae_channels = 128;
     cfg->linear_proj = 0;
+    cfg->text_arch = 0;
 }
 
 extern "C" void sdod_model_config_sd21(sdod_model_config* cfg) {
@@ -821,6 +822,9 @@ extern "C" void sdod_model_config_sd21(sdod_model_config* cfg) {
     cfg->num_heads = 0;
     cfg->head_dim = 64;
     cfg->linear_proj = 1;
+    cfg->text_arch = 1;
+    cfg->text_layers = 23;
+    cfg->text_heads = 16;
 }
 
 extern "C" int sdod_graph_create(void** graph, int kind, const sdod_model_config* cfg, int batch) {

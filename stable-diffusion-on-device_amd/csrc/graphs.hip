@@ -431,28 +431,43 @@ void Graph::build_clip() {
     SDOD_REQUIRE(D % heads == 0 && D / heads == 64, "text encoder head dim must be 64");
     int32_t* ids = (int32_t*)io_alloc(inputs_, (size_t)rows * sizeof(int32_t));
     f16* out = (f16*)io_alloc(outputs_, (size_t)rows * D * sizeof(f16));
-    const int te = P("text_model.embeddings.token_embedding.weight", {cfg_.vocab_size, D}, PK_EMBED);
-    const int pe = P("text_model.embeddings.position_embedding.weight", {L, D}, PK_EMBED);
+    // two checkpoint dialects of the same pre-LN causal transformer (sdod_model_config.text_arch): HF CLIPTextModel names with
+    // separate q/k/v projections and quick-GELU (SD1.x), or open_clip names with a fused in_proj and erf GELU (SD2.x)
+    const bool oc = cfg_.text_arch == 1;
+    const int te = P(oc ? "token_embedding.weight" : "text_model.embeddings.token_embedding.weight", {cfg_.vocab_size, D}, PK_EMBED);
+    const int pe = P(oc ? "positional_embedding" : "text_model.embeddings.position_embedding.weight", {L, D}, PK_EMBED);
     Act x = act(B, 1, L, D);
     {
         const f16* tp = W<f16>(te); const f16* pp = W<f16>(pe);
         emit([=](hipStream_t st) { check_rc2(sdod_embedding_f16(ids, tp, pp, x.p, rows, L, D, st)); });
     }
     for (int l = 0; l < NL; ++l) {
-        const std::string pfx = "text_model.encoder.layers." + std::to_string(l);
-        const int l1w = P(pfx + ".layer_norm1.weight", {D}, PK_VEC), l1b = P(pfx + ".layer_norm1.bias", {D}, PK_VEC);
+        const std::string pfx = (oc ? "transformer.resblocks." : "text_model.encoder.layers.") + std::to_string(l);
+        const int l1w = P(pfx + (oc ? ".ln_1.weight" : ".layer_norm1.weight"), {D}, PK_VEC), l1b = P(pfx + (oc ? ".ln_1.bias" : ".layer_norm1.bias"), {D}, PK_VEC);
         const std::string gw = pfx + ".qkv_w", gb = pfx + ".qkv_b";
-        for (const char* n : {"q_proj", "k_proj", "v_proj"}) P(pfx + ".self_attn." + n + ".weight", {D, D}, PK_LINEAR, gw);
-        for (const char* n : {"q_proj", "k_proj", "v_proj"}) P(pfx + ".self_attn." + n + ".bias", {D}, PK_VEC, gb);
-        const int ow = P(pfx + ".self_attn.out_proj.weight", {D, D}, PK_LINEAR), ob = P(pfx + ".self_attn.out_proj.bias", {D}, PK_VEC);
-        const int l2w = P(pfx + ".layer_norm2.weight", {D}, PK_VEC), l2b = P(pfx + ".layer_norm2.bias", {D}, PK_VEC);
-        const int f1w = P(pfx + ".mlp.fc1.weight", {inter, D}, PK_LINEAR), f1b = P(pfx + ".mlp.fc1.bias", {inter}, PK_VEC);
-        const int f2w = P(pfx + ".mlp.fc2.weight", {D, inter}, PK_LINEAR), f2b = P(pfx + ".mlp.fc2.bias", {D}, PK_VEC);
+        int qkvw = -1, qkvb = -1;
+        if (oc) {
+            qkvw = P(pfx + ".attn.in_proj_weight", {3 * D, D}, PK_LINEAR);
+            qkvb = P(pfx + ".attn.in_proj_bias", {3 * D}, PK_VEC);
+        } else {
+            for (const char* n : {"q_proj", "k_proj", "v_proj"}) P(pfx + ".self_attn." + n + ".weight", {D, D}, PK_LINEAR, gw);
+            for (const char* n : {"q_proj", "k_proj", "v_proj"}) P(pfx + ".self_attn." + n + ".bias", {D}, PK_VEC, gb);
+        }
+        const int ow = P(pfx + (oc ? ".attn.out_proj.weight" : ".self_attn.out_proj.weight"), {D, D}, PK_LINEAR);
+        const int ob = P(pfx + (oc ? ".attn.out_proj.bias" : ".self_attn.out_proj.bias"), {D}, PK_VEC);
+        const int l2w = P(pfx + (oc ? ".ln_2.weight" : ".layer_norm2.weight"), {D}, PK_VEC), l2b = P(pfx + (oc ? ".ln_2.bias" : ".layer_norm2.bias"), {D}, PK_VEC);
+        const int f1w = P(pfx + (oc ? ".mlp.c_fc.weight" : ".mlp.fc1.weight"), {inter, D}, PK_LINEAR), f1b = P(pfx + (oc ? ".mlp.c_fc.bias" : ".mlp.fc1.bias"), {inter}, PK_VEC);
+        const int f2w = P(pfx + (oc ? ".mlp.c_proj.weight" : ".mlp.fc2.weight"), {D, inter}, PK_LINEAR), f2b = P(pfx + (oc ? ".mlp.c_proj.bias" : ".mlp.fc2.bias"), {D}, PK_VEC);
         if (mode_ == DECLARE) continue;
         Act n1 = layer_norm(x, l1w, l1b, 1e-5f);
         f16* qkv = alloc((size_t)rows * 3 * D);
-        { GemmOpt o; o.bias_raw = reinterpret_cast<const float*>(group_base(gb));
-          linear_raw(n1.p, rows, D, reinterpret_cast<const f16*>(group_base(gw)), D, 3 * D, qkv, o); }
+        if (oc) {
+            GemmOpt o; o.bias = qkvb;
+            linear(n1.p, rows, D, qkvw, 3 * D, qkv, o);
+        } else {
+            GemmOpt o; o.bias_raw = reinterpret_cast<const float*>(group_base(gb));
+            linear_raw(n1.p, rows, D, reinterpret_cast<const f16*>(group_base(gw)), D, 3 * D, qkv, o);
+        }
         release(n1);
         f16* a = alloc((size_t)rows * D);
         attention(qkv, qkv + D, qkv + 2 * D, a, B, heads, L, L, D / heads, 3 * D, 3 * D, 3 * D, D, true);
@@ -462,14 +477,15 @@ void Graph::build_clip() {
         release(a); release(x);
         Act n2 = layer_norm(x1, l2w, l2b, 1e-5f);
         f16* f = alloc((size_t)rows * inter);
-        { GemmOpt o; o.bias = f1b; o.act = SDOD_ACT_QUICK_GELU; linear(n2.p, rows, D, f1w, inter, f, o); }
+        { GemmOpt o; o.bias = f1b; o.act = oc ? SDOD_ACT_GELU : SDOD_ACT_QUICK_GELU; linear(n2.p, rows, D, f1w, inter, f, o); }
         release(n2);
         Act x2 = act(B, 1, L, D);
         { GemmOpt o; o.bias = f2b; o.residual = x1.p; linear(f, rows, inter, f2w, D, x2.p, o); }
         release(f); release(x1);
         x = x2;
     }
-    const int fw = P("text_model.final_layer_norm.weight", {D}, PK_VEC), fb = P("text_model.final_layer_norm.bias", {D}, PK_VEC);
+    const int fw = P(oc ? "ln_final.weight" : "text_model.final_layer_norm.weight", {D}, PK_VEC);
+    const int fb = P(oc ? "ln_final.bias" : "text_model.final_layer_norm.bias", {D}, PK_VEC);
     if (mode_ == REAL) {
         const f16* xp = x.p; const float* wp = W<float>(fw); const float* bp = W<float>(fb);
         ops_.push_back(Op{[=](hipStream_t st) { check_rc2(sdod_layer_norm_f16(xp, out, wp, bp, rows, D, 1e-5f, st)); }, "layer_norm", 0,

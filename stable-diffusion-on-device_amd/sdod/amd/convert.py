@@ -38,8 +38,12 @@ def read_checkpoint(path):
     return sd
 
 
+# SD v2.x (public ldm v2 checkpoints): same UNet / VAE prefixes, the text tower is open_clip's model under `.model.`
+GRAPHS_SD21 = dict(GRAPHS, text=('cond_stage_model.model.', 'text_encoder'))
+
+
 def parameter_tables(cfg=None):
-    """{graph: [(name, shape), ...]} of the SD v1.x graphs (no device needed)"""
+    """{graph: [(name, shape), ...]} of the graphs for `cfg` (default SD v1.x; E.sd21_config() for SD v2.1); no device needed"""
     cfg = cfg or E.sd14_config()
     return {'unet': E.UNet(cfg, 2).param_table(), 'temb': E.Temb(cfg, 1).param_table(),
             'vae': E.VaeDecoder(cfg, 1).param_table(), 'text': E.TextEncoder(cfg, 1).param_table()}
@@ -50,9 +54,11 @@ def split_state_dict(sd, tables=None, dtype=torch.float16):
     ValueError on a shape mismatch; entries the graphs do not use (EMA copies, the VAE encoder, position_ids,
     loss / scheduler buffers) are ignored.  Returns ({graph: {name: tensor}}, [unused keys])."""
     tables = tables or parameter_tables()
+    names = {n for n, _ in tables.get('text', [])}
+    prefixes = GRAPHS_SD21 if 'ln_final.weight' in names else GRAPHS      # open_clip text tower => an SD2.x checkpoint
     out, used, missing = {}, set(), []
     for graph, table in tables.items():
-        prefix = GRAPHS[graph][0]
+        prefix = prefixes[graph][0]
         part = {}
         for name, shape in table:
             key = prefix + name
@@ -89,10 +95,12 @@ def main(argv=None):
     ap.add_argument('--ckpt', required=True, help='sd-v1-x .ckpt / .safetensors (ldm key names)')
     ap.add_argument('--out', required=True, help='models_dir to write')
     ap.add_argument('--fp32', action='store_true', help='keep fp32 payloads (the engine converts at load)')
+    ap.add_argument('--model', default='sd14', choices=['sd14', 'sd21'], help='sd21: SD v2.x shapes and open_clip text-tower key names')
     ap.add_argument('--tokenizer-vocab', help='bpe_simple_vocab_16e6.txt.gz, or a directory with HF vocab.json + merges.txt: '
                                               'also write ctokenizer.txt')
     a = ap.parse_args(argv)
-    for p in convert(a.ckpt, a.out, torch.float32 if a.fp32 else torch.float16):
+    cfg = E.sd21_config() if a.model == 'sd21' else None
+    for p in convert(a.ckpt, a.out, torch.float32 if a.fp32 else torch.float16, cfg):
         print('wrote', p)
     if a.tokenizer_vocab:
         from . import tokenizer_file

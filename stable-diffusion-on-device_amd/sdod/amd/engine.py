@@ -16,7 +16,7 @@ class ModelConfig(ctypes.Structure):
     """mirror of `struct sdod_model_config`"""
     _fields_ = [(n, ctypes.c_int) for n in (
         'latent_channels', 'latent_h', 'latent_w', 'model_channels', 'context_dim', 'context_len', 'num_heads',
-        'head_dim', 'vocab_size', 'text_layers', 'text_heads', 'vae_channels', 'linear_proj')]
+        'head_dim', 'vocab_size', 'text_layers', 'text_heads', 'vae_channels', 'linear_proj', 'text_arch')]
 
 
 ENGINE_SYMBOLS = [
@@ -61,7 +61,7 @@ def sd14_config(latent_h=64, latent_w=64):
 
 
 def sd21_config(latent_h=96, latent_w=96):
-    """SD v2.1-768 UNet / VAE shapes (BASELINE config 5); the text encoder (OpenCLIP ViT-H) is not a graph of this library"""
+    """SD v2.1-768 shapes (BASELINE config 5): UNet with 64-wide heads / context 1024, OpenCLIP ViT-H/14 text tower"""
     cfg = ModelConfig()
     _engine().sdod_model_config_sd21(ctypes.byref(cfg))
     cfg.latent_h, cfg.latent_w = latent_h, latent_w

@@ -19,15 +19,13 @@ class Txt2Img:
                  tokenizer=None, with_text_encoder=True, model='sd14', with_vae=True):
         """state_dicts: {'unet': sd, 'temb': sd, 'text': sd, 'vae': sd} in ldm/HF naming (canonical layouts; values may be
         weights.QuantU8 for an int8-weight checkpoint), or models_dir with the .sdodw containers libsdod_setup uses.
-        model='sd21': SD v2.1-768 UNet shapes + v-prediction (BASELINE config 5); its OpenCLIP text encoder is not part of
-        this library, so the conditioning [2, 77, 1024] is supplied by the caller (with_text_encoder is ignored)."""
+        model='sd21': SD v2.1-768 (BASELINE config 5): UNet with 64-wide heads / context 1024, v-prediction, OpenCLIP
+        ViT-H/14 text tower (open_clip key names, penultimate block + ln_final, prompts padded with id 0 after EOT)."""
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.n = images_per_gpu
         self.model = model
         self.v_prediction = model == 'sd21'
-        if model == 'sd21':
-            with_text_encoder = False
         self.cfg = E.sd21_config(latent_hw, latent_hw) if model == 'sd21' else E.sd14_config(latent_hw, latent_hw)
         self.use_hip_graph = use_hip_graph
         self.tokenizer = tokenizer
@@ -60,7 +58,17 @@ class Txt2Img:
         return self.text.out.clone()
 
     def encode_prompt(self, prompt, negative=''):
-        return self.encode_tokens(self.tokenizer.encode(negative), self.tokenizer.encode(prompt))
+        return self.encode_tokens(self._ids(negative), self._ids(prompt))
+
+    def _ids(self, text):
+        """token ids [77]: SOT, tokens, EOT, padding.  CLIP (SD1.x) pads with EOT, as the reference's tokenizer does
+        (tokenizer.cpp:274-275); open_clip's tokenizer (SD2.x) pads with 0 -- the padded positions are part of the context"""
+        ids = np.array(self.tokenizer.encode(text), dtype=np.int64)
+        if self.model == 'sd21':
+            eot = int(ids.max())                       # EOT is the largest id of the vocabulary
+            first = int(np.argmax(ids == eot))
+            ids[first + 1:] = 0
+        return ids
 
     def time_embeddings(self, times):
         """[len(times), E] fp16: time-MLP output projected for every ResBlock, for model times `times` (cached per

@@ -160,3 +160,30 @@ def test_vae_decoder_graph(vae_oracle):
     r = rel_l2(out, ref)
     print('vae 16x16 rel-L2', r, g.stats())
     assert r <= 1e-2, r
+
+
+def test_openclip_text_tower_graph_sd21():
+    """config 5's conditioning: OpenCLIP ViT-H/14 text tower (open_clip names, fused in_proj, erf GELU, penultimate block +
+    ln_final) against the fp32 oracle on the same synthetic weights; prompts padded with id 0 as open_clip's tokenizer does"""
+    from oracle import sd_torch as S
+    from sdod.amd import engine as E, weights as Wt
+    cfg = E.sd21_config()
+    g = E.TextEncoder(cfg, 2)
+    sd = Wt.synthetic_state_dict(g.param_table(), seed=2150)
+    g.load_state_dict(sd)
+    g.finalize()
+    with torch.device('meta'):
+        ref = S.OpenClipTextModel(layers=23, run_layers=23)
+    ref.load_state_dict(sd, assign=True)
+    ids = np.zeros((2, 77), np.int64)
+    ids[:, 0] = 49406
+    ids[0, 1] = 49407
+    ids[1, 1:9] = [320, 1125, 539, 550, 18376, 6765, 320, 4558]; ids[1, 9] = 49407
+    g.ids.copy_(torch.from_numpy(ids.astype(np.int32)))
+    g.execute(True); g.execute(True)
+    with torch.no_grad():
+        want = ref.eval()(torch.from_numpy(ids))
+    out = g.out.float().cpu()
+    r = rel_l2(out, want)
+    print('OpenCLIP-H text tower rel-L2', r, g.stats())
+    assert out.shape == (2, 77, 1024) and torch.isfinite(out).all() and r <= 5e-3, r

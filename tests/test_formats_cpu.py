@@ -250,3 +250,28 @@ def test_sd21_unet_parameter_table_matches_public_architecture():
     want = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
     assert table == want
     assert sum(int(np.prod(s)) for s in table.values()) == 865_910_724
+
+
+def test_sd21_text_tower_table_and_checkpoint_prefixes():
+    """OpenCLIP ViT-H/14 text tower as SD2.x uses it: 23 of the checkpoint's 24 blocks + ln_final; 352,984,064 parameters in
+    the 24-block tower (354,032,640 with the unused text projection), open_clip key names under cond_stage_model.model."""
+    from oracle import sd_torch as S
+    from sdod.amd import convert, engine as E
+    cfg = E.sd21_config()
+    assert (cfg.text_arch, cfg.text_layers, cfg.text_heads) == (1, 23, 16)
+    table = dict(E.TextEncoder(cfg, 2).param_table())
+    with torch.device('meta'):
+        ref = S.OpenClipTextModel()
+    want = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    assert sum(v.numel() for v in ref.state_dict().values()) == 352_984_064
+    assert all(table[k] == want[k] for k in table) and len(table) == 280
+    assert sorted(k for k in want if k not in table) == sorted(k for k in want if k.startswith('transformer.resblocks.23.'))
+    # a v2 checkpoint is split with the open_clip prefix; the last block and the projection stay unused
+    with torch.device('meta'):
+        unet, vae = S.UNetModel(context_dim=1024, head_dim=64, use_linear=True), S.AutoencoderKLDecode()
+    sd = {'model.diffusion_model.' + k: v for k, v in unet.state_dict().items()}
+    sd.update({'first_stage_model.' + k: v for k, v in vae.state_dict().items()})
+    sd.update({'cond_stage_model.model.' + k: v for k, v in ref.state_dict().items()})
+    sd['cond_stage_model.model.text_projection'] = torch.empty(1024, 1024, device='meta')
+    parts, unused = convert.split_state_dict(sd, convert.parameter_tables(cfg))
+    assert len(parts['text']) == 280 and len(unused) == 13 and 'cond_stage_model.model.text_projection' in unused
