@@ -79,6 +79,9 @@ def parse():
     ap.add_argument('--images-per-gpu', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hip-graph', action='store_true')
+    ap.add_argument('--sampler', default='plms', choices=['plms', 'dpm'], help="plms: the headline workload (config 3); dpm: the reference "
+                    "driver's DPM-Solver++(2M), e.g. --sampler dpm --sampler-steps 50 --images-per-gpu 2 = one rank's share of config 4")
+    ap.add_argument('--sampler-steps', type=int, default=20)
     ap.add_argument('--per-step-launches', action='store_true', help='drive the sampler loop from Python (one graph replay per UNet '
                     'evaluation + small launches) instead of replaying the whole trajectory as one device graph')
     return ap.parse_args()
@@ -135,9 +138,8 @@ def main():
             ctx2 = torch.empty(2, cfg.context_len, cfg.context_dim, dtype=torch.float16, device=device)
         ctx2 = broadcast_conditioning(ctx2, 0)
         if args.per_step_launches or args.no_hip_graph:
-            z = pipe.sample_plms(ctx2, x_T, steps=20, guidance=7.5)
-            return pipe.decode(z, mode=1)
-        return pipe.generate_graphed(ctx2, x_T, steps=20, guidance=7.5, sampler='plms')
+            return pipe.generate(ctx2, x_T, steps=args.sampler_steps, guidance=7.5, sampler=args.sampler)
+        return pipe.generate_graphed(ctx2, x_T, steps=args.sampler_steps, guidance=7.5, sampler=args.sampler)
 
     def barrier():
         if dist is not None:
@@ -231,8 +233,9 @@ def main():
             'metric': METRIC, 'value': round(value, 4), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
-            'config': {'workload': 'SD v1.4 txt2img 512x512, 20-step PLMS (21 UNet evals, batch 2 = cond+uncond per image), '
-                                   'CLIP encode + VAE decode + uint8, guidance 7.5',
+            'config': {'workload': ('SD v1.4 txt2img 512x512, 20-step PLMS (21 UNet evals, batch 2 = cond+uncond per image), '
+                                    'CLIP encode + VAE decode + uint8, guidance 7.5') if (args.sampler, args.sampler_steps) == ('plms', 20) else
+                                   f'SD v1.4 txt2img 512x512, {args.sampler_steps}-step {args.sampler.upper()}, CLIP encode + VAE decode + uint8, guidance 7.5',
                        'images_per_gpu': n, 'global_batch': n * world, 'parallelism': f'dp{world} (image shards, 1 RCCL broadcast)',
                        'hip_graph': not args.no_hip_graph,
                        'trajectory_graph': not (args.per_step_launches or args.no_hip_graph)},
