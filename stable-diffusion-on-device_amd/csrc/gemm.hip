@@ -427,7 +427,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
         const int n = n0 + (i * NW + wave) * 8 + lrow;
         b_row[i] = n < p.N ? p.w + (size_t)n * p.ldw + lchunk * 8 : zeros;
     }
-    const int b_step = 0; (void)b_step;
     const int cin = p.c0 + p.c1;
 
     auto issue_tile = [&](int kt, int stage) {
