@@ -1,6 +1,6 @@
 """oracle/gen_golden.py -- generates tests/golden/* from the REFERENCE itself, in this container.
 
-  * dpm_steps{20,50}.json : tables + an update() trajectory from the reference's dpm_solver.cpp
+  * dpm_steps{20,50,1,2,3,8,100}.json : tables + an update() trajectory from the reference's dpm_solver.cpp
                             (compiled in place into oracle/_ref/libref.so by oracle/Makefile)
   * ctokenizer_synthetic.txt + tokenizer_synthetic.json : synthetic vocabulary in the format of
                             gen_tokenizer_file.py:33-42 and token ids from the reference's tokenizer.cpp
@@ -148,7 +148,7 @@ def gen_gn():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     ref = load_ref()
-    gen_dpm(ref, 20)
-    gen_dpm(ref, 50)
+    for steps in (20, 50, 1, 2, 3, 8, 100):   # 20 / 50: the path's configurations; the rest: edge step counts (the reference's
+        gen_dpm(ref, steps)                   # driver only accepts 20, its solver any count)
     gen_tok(ref)
     gen_gn()

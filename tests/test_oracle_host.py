@@ -16,7 +16,7 @@ def bits(a):
     return np.asarray(a, np.float32).view(np.uint32)
 
 
-@pytest.mark.parametrize('steps', [20, 50])
+@pytest.mark.parametrize('steps', [20, 50, 1, 2, 3, 8, 100])
 def test_oracle_dpm_tables_and_trajectory_bit_exact(oracle_lib, golden_dir, steps):
     g = json.load(open(os.path.join(golden_dir, f'dpm_steps{steps}.json')))
     h = oracle_lib.oracle_dpm_create(1000, 0.00085, 0.0120)
