@@ -179,7 +179,8 @@ class Txt2Img:
                 self.generate(s_ctx, s_x, steps, guidance, sampler)          # warm-up: kernel attributes, time embeddings, tuning
                 torch.cuda.synchronize(self.device)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: another thread of the process (a collective backend's watchdog) may touch the runtime meanwhile
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     out = self.generate(s_ctx, s_x, steps, guidance, sampler)
             finally:
                 self.use_hip_graph = keep
