@@ -82,6 +82,8 @@ def parse():
     ap.add_argument('--sampler', default='plms', choices=['plms', 'dpm'], help="plms: the headline workload (config 3); dpm: the reference "
                     "driver's DPM-Solver++(2M), e.g. --sampler dpm --sampler-steps 50 --images-per-gpu 2 = one rank's share of config 4")
     ap.add_argument('--sampler-steps', type=int, default=20)
+    ap.add_argument('--cfg-split', action='store_true', help='latency mode: ranks 2i / 2i+1 compute the uncond / cond half of ONE image '
+                    '(exchange per UNet evaluation); even --gpus only; value counts one image per PAIR')
     ap.add_argument('--per-step-launches', action='store_true', help='drive the sampler loop from Python (one graph replay per UNet '
                     'evaluation + small launches) instead of replaying the whole trajectory as one device graph')
     return ap.parse_args()
@@ -122,13 +124,14 @@ def main():
     sds = {k: Wt.synthetic_state_dict(t, seed=1234 + i) for i, (k, t) in enumerate(tables.items())}
     log('uploading weights / building graphs')
     pipe = Txt2Img(state_dicts=sds, images_per_gpu=n, latent_hw=64, device=f'cuda:{dev_index}',
-                   use_hip_graph=not args.no_hip_graph)
+                   use_hip_graph=not args.no_hip_graph, cfg_split=args.cfg_split)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     if not want_cpu:
         sds = None
     setup_s = time.time() - t_setup
 
-    x_T = torch.cat([initial_latent(42, rank * n + i) for i in range(n)]).to(device)
+    img_owner = rank // 2 if args.cfg_split else rank       # latency mode: both ranks of a pair work on the same images
+    x_T = torch.cat([initial_latent(42, img_owner * n + i) for i in range(n)]).to(device)
     ids_u, ids_c = np.asarray(IDS_UNCOND), np.asarray(IDS_COND)
 
     def one_image():
@@ -228,7 +231,7 @@ def main():
                                       gbs=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['bytes'] else None)
                               for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])})
 
-        value = args.steps * n * world / elapsed
+        value = args.steps * n * (world // 2 if args.cfg_split else world) / elapsed
         out = {
             'metric': METRIC, 'value': round(value, 4), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True,
@@ -236,7 +239,8 @@ def main():
             'config': {'workload': ('SD v1.4 txt2img 512x512, 20-step PLMS (21 UNet evals, batch 2 = cond+uncond per image), '
                                     'CLIP encode + VAE decode + uint8, guidance 7.5') if (args.sampler, args.sampler_steps) == ('plms', 20) else
                                    f'SD v1.4 txt2img 512x512, {args.sampler_steps}-step {args.sampler.upper()}, CLIP encode + VAE decode + uint8, guidance 7.5',
-                       'images_per_gpu': n, 'global_batch': n * world, 'parallelism': f'dp{world} (image shards, 1 RCCL broadcast)',
+                       'images_per_gpu': n, 'global_batch': n * (world // 2 if args.cfg_split else world), 'parallelism': (f'dp{world // 2} x cfg-split pairs (1 broadcast + 1 all-gather per UNet evaluation)' if args.cfg_split
+                                       else f'dp{world} (image shards, 1 RCCL broadcast)'),
                        'hip_graph': not args.no_hip_graph,
                        'trajectory_graph': not (args.per_step_launches or args.no_hip_graph)},
             'unet_step_ms': round(unet_step_ms, 3),

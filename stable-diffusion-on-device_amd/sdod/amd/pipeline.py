@@ -16,7 +16,7 @@ from .samplers import PLMS_ORDERS, PlmsSchedule
 
 class Txt2Img:
     def __init__(self, state_dicts=None, models_dir=None, images_per_gpu=1, latent_hw=64, device='cuda:0', use_hip_graph=True,
-                 tokenizer=None, with_text_encoder=True, model='sd14', with_vae=True):
+                 tokenizer=None, with_text_encoder=True, model='sd14', with_vae=True, cfg_split=False):
         """state_dicts: {'unet': sd, 'temb': sd, 'text': sd, 'vae': sd} in ldm/HF naming (canonical layouts; values may be
         weights.QuantU8 for an int8-weight checkpoint), or models_dir with the .sdodw containers libsdod_setup uses.
         model='sd21': SD v2.1-768 (BASELINE config 5): UNet with 64-wide heads / context 1024, v-prediction, OpenCLIP
@@ -27,9 +27,25 @@ class Txt2Img:
         self.model = model
         self.v_prediction = model == 'sd21'
         self.cfg = E.sd21_config(latent_hw, latent_hw) if model == 'sd21' else E.sd14_config(latent_hw, latent_hw)
+        # latency mode: the two halves of the classifier-free-guidance batch run on TWO GPUs -- even rank =
+        # unconditional, odd rank = conditional -- and exchange their [n,H,W,4] fp16 predictions once per UNet evaluation
+        # (32 KB per image over xGMI); everything after the exchange is computed redundantly, so both ranks hold the image
+        self.cfg_split = bool(cfg_split)
+        self._pair = None
+        if self.cfg_split:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() % 2 == 0):
+                raise RuntimeError('cfg_split needs torch.distributed initialised with an even world size')
+            rank = dist.get_rank()
+            self._half = rank % 2
+            for a in range(0, dist.get_world_size(), 2):           # every rank creates every pair group, in the same order
+                grp = dist.new_group([a, a + 1])
+                if a == rank - self._half:
+                    self._pair = grp
+            self._pair_staged = dist.get_backend() == 'gloo'         # gloo gathers on the host (rehearsals); RCCL on device
         self.use_hip_graph = use_hip_graph
         self.tokenizer = tokenizer
-        self.unet = E.UNet(self.cfg, 2 * self.n, device)
+        self.unet = E.UNet(self.cfg, self.n if cfg_split else 2 * self.n, device)
         self.vae = E.VaeDecoder(self.cfg, 1, device) if with_vae else None
         self.text = E.TextEncoder(self.cfg, 2, device) if with_text_encoder else None
         self._temb_graphs = {}
@@ -89,19 +105,39 @@ class Txt2Img:
     # ------------------------------------------------------------------ one guided eps evaluation
     def _set_context(self, ctx2):
         n = self.n
-        self.unet.ctx[:n].copy_(ctx2[0:1].expand(n, -1, -1))
-        self.unet.ctx[n:].copy_(ctx2[1:2].expand(n, -1, -1))
+        if self.cfg_split:
+            self.unet.ctx.copy_(ctx2[self._half:self._half + 1].expand(n, -1, -1))
+        else:
+            self.unet.ctx[:n].copy_(ctx2[0:1].expand(n, -1, -1))
+            self.unet.ctx[n:].copy_(ctx2[1:2].expand(n, -1, -1))
         self._ctx_fresh = True     # the next UNet execute must redo the cross-attention K/V projections
+
+    def _exchange_halves(self, mine):
+        """[n,H,W,4] fp16 of this rank -> [2n,H,W,4] = (uncond rows ; cond rows), identical on both ranks of the pair"""
+        import torch.distributed as dist
+        both = torch.empty((2 * self.n,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+        if self._pair_staged:
+            host = torch.empty(both.shape, dtype=mine.dtype)
+            dist.all_gather_into_tensor(host, mine.cpu().contiguous(), group=self._pair)
+            both.copy_(host)
+        else:
+            dist.all_gather_into_tensor(both, mine.contiguous(), group=self._pair)
+        return both
 
     def _eps(self, x, temb_row, guidance, mode, v_coef=None):
         """x: fp32 [n,4,H,W]; returns guided eps fp32 [n,4,H,W].  Batch rows: [uncond x n ; cond x n] (ldm order).
         v_coef = (sqrt(abar_t), sqrt(1 - abar_t)) for a v-prediction model: the guided output is v, eps follows from it."""
         n = self.n
-        self.unet.x[:n].copy_(x); self.unet.x[n:].copy_(x)
-        self.unet.temb.copy_(temb_row.unsqueeze(0).expand(2 * n, -1))
+        if self.cfg_split:
+            self.unet.x.copy_(x)
+            self.unet.temb.copy_(temb_row.unsqueeze(0).expand(n, -1))
+        else:
+            self.unet.x[:n].copy_(x); self.unet.x[n:].copy_(x)
+            self.unet.temb.copy_(temb_row.unsqueeze(0).expand(2 * n, -1))
         self.unet.execute(self.use_hip_graph, static_unchanged=not self._ctx_fresh)
         self._ctx_fresh = False
-        out = ops.cfg_combine(self.unet.eps, guidance, uncond_first=True, mode=mode)
+        eps = self._exchange_halves(self.unet.eps) if self.cfg_split else self.unet.eps
+        out = ops.cfg_combine(eps, guidance, uncond_first=True, mode=mode)
         if v_coef is not None:
             out = ops.lincomb4([out, x], [v_coef[0], v_coef[1]], 1.0)
         return out
@@ -167,6 +203,8 @@ class Txt2Img:
         step, so the GPU never waits for Python between steps (2-3 ms per image at 20 steps).  The sequence is static for a
         given (sampler, steps, guidance, batch): it is captured once from the ordinary eager code path (so it is the same
         kernels on the same buffers, bit for bit) and cached; ctx2 / x_T are copied into the graph's static inputs."""
+        if self.cfg_split:                 # a collective per evaluation cannot live inside one captured graph
+            return self.generate(ctx2, x_T, steps, guidance, sampler)
         key = (sampler, int(steps), float(guidance), tuple(x_T.shape))
         cache = self.__dict__.setdefault('_traj', {})
         if key not in cache:
