@@ -240,6 +240,13 @@ __global__ __launch_bounds__(NT) void gn_small_kernel(const GnP p, int sw) {
     const int cps = sw / 8;
     const int total = p.HW * cps;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the affine parameters of "my" channel are requested first: their L2 round trip hides behind the slab load instead of
+    // standing alone between the statistics and the normalisation
+    float pw = 1.0f, pb = 0.0f;
+    if (tid < sw && p.w != nullptr) {
+        pw = p.w[cbase + tid];
+        pb = p.b[cbase + tid];
+    }
     for (int i = tid; i < total; i += NT) {
         const int pix = i / cps, cc = i - pix * cps;
         const T* src = gn_src<T>(p, n, pix, cbase + cc * 8);
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(NT) void gn_small_kernel(const GnP p, int sw) {
         const float mean = (float)slab[gi * p.Cg] + md;
         const float rstd = 1.0f / sqrtf(var + p.eps);
         const int ch = cbase + c;
-        const float w = p.w ? p.w[ch] : 1.0f, bb = p.b ? p.b[ch] : 0.0f;
+        const float w = c == tid ? pw : (p.w ? p.w[ch] : 1.0f), bb = c == tid ? pb : (p.b ? p.b[ch] : 0.0f);
         sc[c] = rstd * w;
         sh[c] = bb - mean * rstd * w;
     }
