@@ -149,6 +149,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if not (args.per_step_launches or args.no_hip_graph):
+        one_image()            # builds (captures) the trajectory graph: part of setup, like tile tuning, also when --warmup 0
+        barrier()
+        setup_s = time.time() - t_setup
     log(f'setup done in {setup_s:.1f}s; warm-up x{args.warmup}')
     for _ in range(args.warmup):
         img = one_image()
