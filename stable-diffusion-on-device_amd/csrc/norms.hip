@@ -363,7 +363,7 @@ bool gn_try_small(GnP& p, hipStream_t st) {
     return true;
 }
 
-constexpr int GN_INLINE_CHUNKS = 64; // up to here the apply pass reduces the partials itself (two launches per GroupNorm)
+constexpr int GN_INLINE_CHUNKS = 128; // up to here the apply pass reduces the partials itself (two launches per GroupNorm)
 
 template <typename T>
 void gn_launch(GnP& p, hipStream_t st) {
