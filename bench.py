@@ -89,12 +89,45 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` from a bare shell: start N fresh worker processes (one rank per GPU) with the rendezvous
+    environment torch.distributed.run would set, BEFORE this process touches the GPU (it never does); rank 0's JSON line
+    goes to the inherited stdout.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                break              # a rank that died leaves its peers waiting in a collective
+            time.sleep(0.2)
+        rc = max(abs(p.poll() or 0) for p in procs if p.poll() is not None)
+    finally:
+        for p in procs:            # end exactly our own children, by handle
+            if p.poll() is None:
+                p.terminate()
+                rc = rc or 1
+        for p in procs:
+            p.wait()
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks'
     # functional rehearsal of the N>1 path on a one-GPU box: SDOD_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0 and
     # SDOD_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); never used for reported numbers
     share = os.environ.get('SDOD_BENCH_SHARE_DEVICE') == '1'

@@ -97,6 +97,8 @@ SDOD_API int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream);
 SDOD_API size_t sdod_gemm_workspace_bytes(const sdod_gemm_desc* d);
 /* which tile configuration (1: 128x128, 2: 128x64, 3: 64x64, 4: 256x16, 5: 64x128) and split-K factor the call would use */
 SDOD_API int sdod_gemm_plan(const sdod_gemm_desc* d, int* tile, int* splits);
+/* number of tile configurations (valid `tile` values are 1..this); a tune table naming anything else is stale */
+SDOD_API int sdod_gemm_num_tiles(void);
 /* developer aid: average duration in ms of `iters` back-to-back launches (HIP events on `stream`) */
 SDOD_API int sdod_gemm_time(const sdod_gemm_desc* d, void* stream, int iters, float* ms_avg);
 /* Same, with cold caches: before every timed launch a sweep of `scratch` (>= 64 MiB; use >= 512 MiB to clear the 256 MiB

@@ -166,16 +166,18 @@ __global__ void timestep_features_kernel(const float* t, f16* y, int n, int dim)
     }
 }
 
-// fp16 rows, fp32 math; each thread keeps <= 4 chunks of its row in registers
+// fp16 rows, fp32 math; each thread keeps <= NCH chunks of its row in registers (NCH = 4: rows up to 8192 columns, the
+// SD v1 VAE attention at 64x64; NCH = 8: up to 16384, the 96x96 latent of SD v2.1-768)
+template <int NCH>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* x, f16* y, int M, int N) {
     __shared__ float red[8];
     const int row = blockIdx.x;
     const int cp = N / 8;
     const f16* xr = x + (size_t)row * N;
-    f16x8 v[4];
+    f16x8 v[NCH];
     float mx = -3.0e38f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int ch = threadIdx.x + 256 * i;
         if (ch < cp) {
             v[i] = ldg8(xr + ch * 8);
@@ -189,9 +191,9 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* x, f16* y,
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
-    float ev[4][8];
+    float ev[NCH][8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int ch = threadIdx.x + 256 * i;
         if (ch < cp) {
 #pragma unroll
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* x, f16* y,
     const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
     f16* yr = y + (size_t)row * N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int ch = threadIdx.x + 256 * i;
         if (ch < cp) {
             f16x8 o;
@@ -383,8 +385,9 @@ extern "C" int sdod_timestep_features_f16(const float* t, void* y, int n, int di
 
 extern "C" int sdod_softmax_rows_f16(const void* x, void* y, int m, int n, void* stream) {
     SDOD_TRY
-    SDOD_REQUIRE(x && y && m > 0 && n > 0 && n % 8 == 0 && n <= 8192, "softmax rows need N % 8 == 0 and N <= 8192");
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, m, n);
+    SDOD_REQUIRE(x && y && m > 0 && n > 0 && n % 8 == 0 && n <= 16384, "softmax rows need N % 8 == 0 and N <= 16384");
+    if (n <= 8192) hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3(m), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, m, n);
+    else hipLaunchKernelGGL(softmax_rows_kernel<8>, dim3(m), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, m, n);
     SDOD_HIP_CHECK(hipGetLastError());
     return 0;
     SDOD_CATCH

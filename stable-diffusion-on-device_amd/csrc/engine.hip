@@ -3,6 +3,7 @@
 
 #include <cstdio>
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -272,7 +273,7 @@ void Graph::set_param(const std::string& name, const void* data, int dtype, cons
 // .sdodw container: "SDODW001", u64 count, then per tensor {u32 name_len, name, u32 dtype, u32 ndim, u64 dims[ndim],
 // u64 offset, u64 nbytes}; payloads at absolute file offsets.  Written by sdod.amd.weights.save().
 void Graph::load_file(const std::string& path, const std::string& prefix) {
-    allocate_weights();
+    // (device memory is claimed by the first set_param: a malformed container is rejected before any device call)
     int fd = ::open(path.c_str(), O_RDONLY);
     SDOD_REQUIRE(fd >= 0, "cannot open weight file " + path);
     struct stat stt;
@@ -308,7 +309,17 @@ void Graph::load_file(const std::string& path, const std::string& prefix) {
         for (uint32_t i = 0; i < nd; ++i) { uint64_t d; std::memcpy(&d, base + pos, 8); pos += 8; dims[i] = (int64_t)d; }
         uint64_t off, nb;
         std::memcpy(&off, base + pos, 8); std::memcpy(&nb, base + pos + 8, 8); pos += 16;
-        SDOD_REQUIRE(off + nb <= fsize, "tensor payload out of range in " + path);
+        SDOD_REQUIRE(off <= fsize && nb <= fsize - off, "tensor payload out of range in " + path); // no u64 wrap
+        SDOD_REQUIRE(dt == SDOD_F16 || dt == SDOD_F32 || dt == SDOD_U8Q, "bad dtype for '" + name + "' in " + path);
+        // the payload must hold exactly prod(dims) elements (+ the {scale, offset} prefix of an affine-uint8 tensor):
+        // set_param reads that many bytes from the mapping
+        uint64_t numel = 1;
+        for (uint32_t i = 0; i < nd; ++i) {
+            SDOD_REQUIRE(dims[i] > 0 && (uint64_t)dims[i] <= (uint64_t(1) << 40) / numel, "bad dims for '" + name + "' in " + path);
+            numel *= (uint64_t)dims[i];
+        }
+        const uint64_t want = dt == SDOD_U8Q ? 8 + numel : numel * (dt == SDOD_F16 ? 2 : 4);
+        SDOD_REQUIRE(nb == want, "payload size of '" + name + "' does not match its dims in " + path);
         if (name.compare(0, prefix.size(), prefix) != 0) continue;
         const std::string local = name.substr(prefix.size());
         if (!pindex_.count(local)) continue;
@@ -410,32 +421,52 @@ struct ShapeKey {
     int v[12];
     bool operator<(const ShapeKey& o) const { return std::lexicographical_compare(v, v + 12, o.v, o.v + 12); }
 };
-// SDOD_TUNE_CACHE=<file>: picks are read from / appended to a text file (13 integers per line: the shape key, then
-// tile + 1000 * split_k), so that a later process -- a profiling run, a service restart -- builds its graphs without
-// re-timing anything and with the SAME launch list.  Picks depend on the build and the device: delete the file with either.
+// Picks come from two text files (13 integers per line: the shape key, then tile + 1000 * split_k):
+//   * the SHIPPED table tune/gfx950.tune next to lib/ (located through dladdr): the picks for the headline shapes, made on
+//     an MI355X by tools/make_tune_cache.py and committed, so that every process -- bench, rocprofv3 passes, the C API, a
+//     service restart -- builds the SAME launch list without timing anything, and images are bit-identical across processes
+//     (SDOD_TUNE_DEFAULT=0 ignores it);
+//   * SDOD_TUNE_CACHE=<file>: read after (so it overrides) the shipped table; shapes found in neither are timed once and
+//     appended to it.  Picks depend on the build and the device: regenerate the table when the tiles change.
 const char* tune_cache_path() {
     const char* e = std::getenv("SDOD_TUNE_CACHE");
     return (e && e[0]) ? e : nullptr;
+}
+std::string shipped_tune_path() {
+    const char* e = std::getenv("SDOD_TUNE_DEFAULT");
+    if (e && e[0] == '0') return "";
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<const void*>(&sdod_model_config_sd14), &info) || !info.dli_fname) return "";
+    std::string lib = info.dli_fname; // .../stable-diffusion-on-device_amd/lib/libsdod.so
+    const size_t a = lib.rfind('/');
+    if (a == std::string::npos) return "";
+    const size_t b = lib.rfind('/', a - 1);
+    if (b == std::string::npos) return "";
+    return lib.substr(0, b) + "/tune/gfx950.tune";
+}
+void tune_cache_read(const char* path, std::map<ShapeKey, int>& c) {
+    FILE* f = std::fopen(path, "r");
+    if (!f) return;
+    ShapeKey k;
+    int v;
+    for (;;) {
+        int got = 0;
+        for (int i = 0; i < 12; ++i) got += std::fscanf(f, "%d", &k.v[i]) == 1;
+        got += std::fscanf(f, "%d", &v) == 1;
+        if (got != 13) break;
+        const int tile = v % 1000, split = v / 1000;
+        if (tile >= 1 && tile <= sdod_gemm_num_tiles() && split >= 1 && split <= 64) c[k] = v; // a stale table is re-tuned, not trusted
+    }
+    std::fclose(f);
 }
 std::map<ShapeKey, int>& tune_cache() {
     static std::map<ShapeKey, int> c;
     static bool loaded = false;
     if (!loaded) {
         loaded = true;
-        if (const char* path = tune_cache_path()) {
-            if (FILE* f = std::fopen(path, "r")) {
-                ShapeKey k;
-                int v;
-                for (;;) {
-                    int got = 0;
-                    for (int i = 0; i < 12; ++i) got += std::fscanf(f, "%d", &k.v[i]) == 1;
-                    got += std::fscanf(f, "%d", &v) == 1;
-                    if (got != 13) break;
-                    c[k] = v;
-                }
-                std::fclose(f);
-            }
-        }
+        const std::string shipped = shipped_tune_path();
+        if (!shipped.empty()) tune_cache_read(shipped.c_str(), c);
+        if (const char* path = tune_cache_path()) tune_cache_read(path, c);
     }
     return c;
 }

@@ -909,6 +909,8 @@ extern "C" size_t sdod_gemm_workspace_bytes(const sdod_gemm_desc* d) {
     return pl.splits > 1 ? (size_t)pl.splits * d->M * d->N * sizeof(float) : 0;
 }
 
+extern "C" int sdod_gemm_num_tiles(void) { return kNumTiles; }
+
 extern "C" int sdod_gemm_plan(const sdod_gemm_desc* d, int* tile, int* splits) {
     if (!d || d->K <= 0 || d->K % BK) return sdod::INVALID_ARGUMENT;
     const Plan pl = make_plan(d);

@@ -349,7 +349,7 @@ Act Graph::vae_attn_block(const std::string& pfx, const Act& x) {
     const int vw = P(pfx + ".v.weight", {C, C, 1, 1}, PK_CONV1), vb = P(pfx + ".v.bias", {C}, PK_VEC);
     const int pw = P(pfx + ".proj_out.weight", {C, C, 1, 1}, PK_CONV1), pb = P(pfx + ".proj_out.bias", {C}, PK_VEC);
     if (mode_ == DECLARE) return act(x.n, x.h, x.w, C);
-    SDOD_REQUIRE(L % 64 == 0 && L <= 8192, "VAE attention needs H*W % 64 == 0 and <= 8192");
+    SDOD_REQUIRE(L % 64 == 0 && L <= 16384, "VAE attention needs H*W % 64 == 0 and <= 16384");
 
     Act g = group_norm(x, nullptr, nw, nb, 1e-6f, false);
     f16* qk = alloc((size_t)rows * 2 * C);

@@ -136,7 +136,7 @@ class Graph:
                 self.set_param(name, sd[key])
 
     def load_file(self, path, prefix=''):
-        with torch.cuda.device(self.device):
+        with self._on_device():
             check(self._lib.sdod_graph_load_file(self._h, path.encode(), prefix.encode()))
 
     def finalize(self):

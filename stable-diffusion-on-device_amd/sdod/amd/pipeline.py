@@ -232,7 +232,7 @@ class Txt2Img:
 def broadcast_conditioning(ctx2, src=0):
     """the one collective of the path: CLIP output [2,77,768] fp16 (236,544 B) from rank `src` to every rank over RCCL"""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.broadcast(ctx2, src=src)
     return ctx2
 

@@ -275,3 +275,36 @@ def test_sd21_text_tower_table_and_checkpoint_prefixes():
     sd['cond_stage_model.model.text_projection'] = torch.empty(1024, 1024, device='meta')
     parts, unused = convert.split_state_dict(sd, convert.parameter_tables(cfg))
     assert len(parts['text']) == 280 and len(unused) == 13 and 'cond_stage_model.model.text_projection' in unused
+
+
+def _container(entries):
+    """raw .sdodw bytes from (name, dtype, dims, offset, nbytes) records; payload region = 4 KiB of zeros"""
+    head = b'SDODW001' + struct.pack('<Q', len(entries))
+    for name, dt, dims, off, nb in entries:
+        nm = name.encode()
+        head += struct.pack('<I', len(nm)) + nm + struct.pack('<II', dt, len(dims))
+        head += b''.join(struct.pack('<Q', d & (2 ** 64 - 1)) for d in dims) + struct.pack('<QQ', off & (2 ** 64 - 1), nb & (2 ** 64 - 1))
+    return head + bytes(4096)
+
+
+@pytest.mark.parametrize('entry,what', [
+    (('time_embed.0.bias', 1, [1280], 2 ** 64 - 64, 128), 'out of range'),          # offset + nbytes wraps around in u64
+    (('time_embed.0.bias', 1, [1280], 512, 1 << 40), 'out of range'),               # payload runs past the end of the file
+    (('time_embed.0.bias', 1, [1280], 512, 64), 'does not match its dims'),         # truncated payload: set_param would over-read
+    (('time_embed.0.bias', 2, [1280], 512, 1280), 'does not match its dims'),       # affine uint8 without its {scale, offset} prefix
+    (('time_embed.0.bias', 1, [0], 512, 0), 'bad dims'),
+    (('time_embed.0.bias', 1, [-5], 512, 20), 'bad dims'),
+    (('time_embed.0.bias', 7, [128], 512, 512), 'bad dtype'),
+])
+def test_malformed_weight_container_is_rejected_before_any_read(tmp_path, entry, what):
+    """Graph::load_file validates every record against the file size and its own dims (ADVICE r1: a truncated / hostile
+    container must yield LIBSDOD_INVALID_ARGUMENT, not an out-of-bounds read inside libsdod_setup).  No GPU needed: the
+    record is rejected before device memory is claimed."""
+    from sdod.amd import engine as E
+    from sdod.amd._lib import SdodError
+    path = tmp_path / 'temb.sdodw'
+    path.write_bytes(_container([entry]))
+    g = E.Temb(E.sd14_config(64, 64), 1)
+    with pytest.raises(SdodError) as ei:
+        g.load_file(str(path))
+    assert ei.value.code == 2 and what in str(ei.value), str(ei.value)

@@ -236,6 +236,12 @@ def test_conv_small_cin_via_im2col():
     (2, 4096, 320, 32, torch.float16, True), (2, 64, 2560, 32, torch.float16, True), (1, 16384, 128, 32, torch.float16, False),
     (2, 1024, 960, 32, torch.float16, True), (1, 100, 64, 32, torch.float32, False), (3, 7, 8, 2, torch.float32, True),
     (2, 256, 1920, 32, torch.float16, False),
+    # the VAE decoder's big maps (256^2 x 256 ch, 512^2 x 128 ch): > 128 statistics chunks per image, i.e. the
+    # gn_collapse_kernel path of norms.hip; (2, 65536, 256) is its batched variant
+    (1, 65536, 256, 32, torch.float16, True), (1, 262144, 128, 32, torch.float16, True), (2, 65536, 256, 32, torch.float16, False),
+    (2, 1024, 320, 32, torch.float16, True), (2, 1024, 640, 32, torch.float16, True), (2, 256, 1280, 32, torch.float16, True),
+    (4, 4096, 320, 32, torch.float16, True), (2, 9216, 320, 32, torch.float16, True), (2, 2304, 640, 32, torch.float16, False),
+    (2, 576, 1280, 32, torch.float16, True), (2, 144, 1280, 32, torch.float16, True),
 ])
 def test_group_norm(n, hw, c, g, dtype, silu):
     from sdod.amd import ops
@@ -363,6 +369,8 @@ def test_elementwise_and_layout():
     assert torch.equal(back.cpu(), nhwc.cpu().float().permute(0, 3, 1, 2))
     s = rnd((64, 4096), 86, 3.0)
     check(ops.softmax_rows(s.to(d)), torch.softmax(s.float(), -1), name='softmax')
+    s = rnd((16, 9216), 90, 3.0)       # SD v2.1-768 VAE attention row (96x96 latent): the 8-chunk variant
+    check(ops.softmax_rows(s.to(d)), torch.softmax(s.float(), -1), name='softmax 9216')
     ids = torch.randint(0, 1000, (2, 77), generator=torch.Generator().manual_seed(87), dtype=torch.int32)
     table = rnd((1000, 768), 88); pos = rnd((77, 768), 89)
     check(ops.embedding(ids.to(d), table.to(d), pos.to(d)), table[ids.long()].float() + pos.float()[None], name='embedding')

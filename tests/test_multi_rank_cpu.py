@@ -62,3 +62,28 @@ def test_plms_schedule_indexing_exact():
     assert PLMS_ORDERS[3] == ((55.0, -59.0, 37.0, -9.0), 24.0)
     s50 = PlmsSchedule(50)
     assert s50.timesteps[0] == 1 and s50.timesteps[-1] == 981 and s50.steps == 50
+
+
+def test_bench_launcher_spawns_one_rank_per_gpu(tmp_path):
+    """`python bench.py --gpus N` from a bare shell (no torchrun): spawn_ranks starts N fresh processes with the rendezvous
+    environment; exercised here with a stand-in worker that joins a gloo group and reports what it saw."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    worker = tmp_path / 'worker.py'
+    worker.write_text(
+        "import json, os, sys\n"
+        "import torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "t = torch.tensor([float(dist.get_rank() + 1)])\n"
+        "dist.all_reduce(t)\n"
+        "open(os.path.join(sys.argv[1], 'rank%d.json' % dist.get_rank()), 'w').write(json.dumps(\n"
+        "    {k: os.environ[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR')} | {'sum': float(t)}))\n"
+        "dist.destroy_process_group()\n")
+    assert bench.spawn_ranks(2, [str(worker), str(tmp_path)]) == 0
+    got = [json.loads((tmp_path / f'rank{r}.json').read_text()) for r in range(2)]
+    assert [g['RANK'] for g in got] == ['0', '1'] and [g['LOCAL_RANK'] for g in got] == ['0', '1']
+    assert all(g['WORLD_SIZE'] == '2' and g['MASTER_ADDR'] == '127.0.0.1' and g['sum'] == 3.0 for g in got)
+    bad = tmp_path / 'bad.py'
+    bad.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(3)\ntime.sleep(60)\n")
+    assert bench.spawn_ranks(2, [str(bad)]) != 0          # a dead rank ends the job instead of hanging its peers

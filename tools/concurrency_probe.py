@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer experiment (GPU box): does running the cond and uncond halves of the CFG batch as TWO concurrent batch-1
 graph replays (two streams) beat ONE batch-2 replay?  Kernel launch/drain phases of one chain could overlap the
-other chain's work.  usage: python tools/concurrency_test.py"""
+other chain's work.  usage: python tools/concurrency_probe.py"""
 import os
 import sys
 import time

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Regenerate the shipped GEMM tile table (stable-diffusion-on-device_amd/tune/gfx950.tune) on an MI355X.
+
+Builds every graph of the configurations the benches and the GPU tests use with the shipped table ignored
+(SDOD_TUNE_DEFAULT=0) and SDOD_TUNE_CACHE pointing at a fresh file, so every distinct GEMM shape is timed cold-cache once
+(engine.hip: emit_gemm) and its pick appended.  Copy the result over tune/gfx950.tune and commit it: from then on
+every process builds the same launch lists without timing anything.
+
+usage (GPU box):  python tools/make_tune_cache.py gpurun_out/gfx950.tune [--quick]
+NEVER run under a profiler (timing noise would be baked into the picks)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'stable-diffusion-on-device_amd'))
+
+out = os.path.abspath(sys.argv[1])
+quick = '--quick' in sys.argv
+if os.path.exists(out):
+    os.remove(out)
+os.makedirs(os.path.dirname(out), exist_ok=True)
+os.environ['SDOD_TUNE_CACHE'] = out
+os.environ['SDOD_TUNE_DEFAULT'] = '0'
+
+import torch  # noqa: E402
+from sdod.amd import engine as E, weights as Wt  # noqa: E402
+
+T0 = time.time()
+
+
+def build(cls, cfg, batch, seed, label):
+    g = cls(cfg, batch)
+    g.load_state_dict(Wt.synthetic_state_dict(g.param_table(), seed=seed))
+    g.finalize()
+    torch.cuda.synchronize()
+    n = sum(1 for _ in open(out)) if os.path.exists(out) else 0
+    print(f'[{time.time() - T0:6.1f}s] {label}: {g.stats()["launches"]} launches; table now {n} shapes', flush=True)
+    del g
+
+
+# headline (configs 2/3), config 4's per-rank share (batch 4), latency mode (batch 1)
+c64 = E.sd14_config(64, 64)
+for b in (2, 4, 1):
+    build(E.UNet, c64, b, 1234, f'sd14 unet 64x64 b{b}')
+build(E.VaeDecoder, c64, 1, 1236, 'sd14 vae 64x64')
+build(E.TextEncoder, c64, 2, 1237, 'clip-L b2')
+build(E.TextEncoder, c64, 1, 1237, 'clip-L b1')
+for b in (1, 2, 4):
+    build(E.Temb, c64, b, 1235, f'temb b{b}')
+build(E.Temb, c64, 20, 1235, 'temb b20')
+build(E.Temb, c64, 50, 1235, 'temb b50')
+if not quick:
+    # config 5 (SD v2.1-768) and the reduced sizes the GPU tests run
+    c96 = E.sd21_config(96, 96)
+    build(E.UNet, c96, 2, 2100, 'sd21 unet 96x96 b2')
+    build(E.VaeDecoder, c96, 1, 1236, 'vae 96x96')
+    build(E.TextEncoder, c96, 2, 2102, 'openclip-H b2')
+    build(E.Temb, c96, 1, 2101, 'sd21 temb b1')
+    build(E.Temb, c96, 20, 2101, 'sd21 temb b20')
+    c16 = E.sd14_config(16, 16)
+    for b in (2, 4, 1):
+        build(E.UNet, c16, b, 1234, f'sd14 unet 16x16 b{b}')
+    build(E.VaeDecoder, c16, 1, 1236, 'vae 16x16')
+    c24 = E.sd21_config(24, 24)
+    build(E.UNet, c24, 2, 2100, 'sd21 unet 24x24 b2')
+print(f'done: {out}')
