@@ -117,6 +117,33 @@ SDOD_API int sdod_group_norm_nhwc(const void* x, const void* x2, void* y, const 
                                   int n, int hw, int c0, int c1, int groups, float eps, int silu, int dtype,
                                   void* workspace, void* stream);
 
+/* GroupNorm whose source-0 tensor is still in split-K form: the producing GEMM ran with phase = 1 (fp32 partial slabs only),
+ * and this call does what its phase 2 (splitk_reduce + fused epilogue) would have done -- x = fp16(act(alpha * sum_s partial
+ * + bias + bias2 + row_bias[image])) + residual, same arithmetic and rounding points -- while loading the group: x is
+ * written to x_out ([n*hw][c0], dense) for its later readers and GroupNorm(+SiLU) of (x | x2) goes to y, in ONE launch.
+ * sdod_gemm_reduce_info fills the descriptor from the GEMM's; sdod_group_norm_reduce_ok tells whether the one-launch
+ * (image, group) kernel takes the shape (otherwise run phase 2 and the plain GroupNorm). */
+typedef struct sdod_gn_reduce {
+    const void* partial;   /* fp32 [splits][M][N] */
+    int splits;
+    size_t slab_floats;    /* M * N */
+    const void* bias;      /* fp32 [N] or NULL */
+    const void* bias2;     /* fp32 [N] or NULL */
+    const void* row_bias;  /* fp16 [n_img][ld_row_bias] or NULL (rows_per_img must equal hw) */
+    int ld_row_bias;
+    const void* residual;  /* fp16 [M][ldr] or NULL */
+    int ldr;
+    void* x_out;           /* fp16 [M][N] */
+    float alpha;
+    int act;
+    int M, N;
+} sdod_gn_reduce;
+SDOD_API int sdod_gemm_reduce_info(const sdod_gemm_desc* d, sdod_gn_reduce* out);
+SDOD_API int sdod_group_norm_reduce_ok(int hw, int c0, int c1, int groups);
+SDOD_API int sdod_group_norm_reduce_nhwc(const sdod_gn_reduce* red, const void* x2, void* y, const float* weight,
+                                         const float* bias, int n, int hw, int c0, int c1, int groups, float eps, int silu,
+                                         void* stream);
+
 /* Folds a LayerNorm (gamma, beta over K) into the Linear that consumes it, in place: t_out[n] = sum_k beta[k]*W[n][k]
  * (+ bias_in[n]); W[n][k] <- fp16(W[n][k]*gamma[k]); s_out[n] = sum_k W'[n][k].  Used once per weight at graph build. */
 SDOD_API int sdod_ln_fold_f16(void* w, int n, int k, int ldw, const float* gamma, const float* beta, const float* bias_in,

@@ -179,6 +179,29 @@ private:
     // ---- model blocks
     Act res_block(const std::string& pfx, const Act& x, const Act* x2, int cout, const f16* emb_all, int emb_ld, int& emb_off);
     std::vector<Op>& sink() { return to_static_ ? static_ops_ : ops_; }
+    // A split-K GEMM whose reduce + epilogue launch (phase 2) has not been emitted yet: if the tensor's first consumer is a
+    // GroupNorm the (image, group) kernel takes over that work (sdod_group_norm_reduce_nhwc: one launch instead of three);
+    // every other emitter flushes it first.  At most one is pending: the partial slabs live in the shared workspace ws_.
+    struct PendingReduce {
+        bool active = false;
+        sdod_gemm_desc d{};      // phase = 2
+        double bytes = 0;
+        std::string detail;
+    } pending_;
+    void flush_pending();
+    // The deferred phase 2 still READS the GEMM's residual operand, so a tensor that is a residual must not return to the
+    // arena before its consumer has been emitted: release_after_consumer() parks it until the next emitter has settled
+    // (same order in the DECLARE / DRY / REAL passes, so the arena plan stays exact).
+    std::vector<const void*> parked_;
+    void release_after_consumer(const Act& a) { parked_.push_back(a.p); }
+    void drain_parked() {
+        for (const void* p : parked_) release(p);
+        parked_.clear();
+    }
+    void settle() {
+        flush_pending();
+        drain_parked();
+    }
     Act spatial_transformer(const std::string& pfx, const Act& x, const Act& ctx);
     Act vae_res_block(const std::string& pfx, const Act& x, int cout);
     Act vae_attn_block(const std::string& pfx, const Act& x);
@@ -189,6 +212,7 @@ private:
     std::vector<std::pair<std::string, int>> unet_res_blocks() const; // (prefix, cout) in declaration order
     const char* group_base(const std::string& group) const;
     void emit(std::function<void(hipStream_t)> fn, const char* label = "elementwise", double flops = 0, double bytes = 0) {
+        settle();
         if (mode_ == REAL) sink().push_back(Op{std::move(fn), label, flops, bytes, ""});
     }
 

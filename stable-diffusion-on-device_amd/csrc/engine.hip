@@ -359,6 +359,7 @@ f16* Graph::alloc(size_t halves) {
 
 void Graph::release(const void* p) {
     if (!p) return;
+    if (pending_.active && pending_.d.residual == p) flush_pending(); // the deferred reduce still reads this tensor
     char* base = mode_ == REAL ? arena_base_ : kFakeBase;
     const size_t off = (size_t)(reinterpret_cast<const char*>(p) - base);
     auto it = used_.find(off);
@@ -499,7 +500,15 @@ ShapeKey key_of(const sdod_gemm_desc& d) {
 }
 } // namespace
 
+void Graph::flush_pending() {
+    if (!pending_.active) return;
+    pending_.active = false;
+    const sdod_gemm_desc d2 = pending_.d;
+    sink().push_back(Op{[d2](hipStream_t st) { check_rc(sdod_gemm_f16(&d2, st)); }, "splitk_reduce", 0.0, pending_.bytes, pending_.detail});
+}
+
 void Graph::emit_gemm(sdod_gemm_desc d) {
+    settle();
     if (mode_ == DECLARE) return;
     const bool tune = autotune_enabled() && d.N > 16;
     if (tune) {
@@ -585,8 +594,13 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
         d2.phase = 2;
         const double part = (double)splits * d.M * d.N * 4;
         sink().push_back(Op{[d1](hipStream_t st) { check_rc(sdod_gemm_f16(&d1, st)); }, label, fl, by + part, detail});
-        sink().push_back(Op{[d2](hipStream_t st) { check_rc(sdod_gemm_f16(&d2, st)); }, "splitk_reduce", 0.0,
-                            part + (double)d.M * d.N * 2 * (d.residual ? 2 : 1), detail});
+        // phase 2 is deferred: a GroupNorm that consumes d.out next folds it into its load (group_norm()), anything else
+        // emits it as the stand-alone reduce launch
+        pending_.active = true;
+        pending_.d = d2;
+        pending_.bytes = part + (double)d.M * d.N * 2 * (d.residual ? 2 : 1);
+        pending_.detail = detail;
+        if (to_static_ || std::getenv("SDOD_NO_GN_REDUCE")) flush_pending();
         return;
     }
     sink().push_back(Op{[d](hipStream_t st) { check_rc(sdod_gemm_f16(&d, st)); }, label, fl, by, detail});
@@ -672,22 +686,37 @@ Act Graph::conv(const Act& x, const Act* x2, int w, int cout, int ksize, int str
 }
 
 Act Graph::group_norm(const Act& x, const Act* x2, int gw, int gb, float eps, bool silu) {
-    Act y = act(x.n, x.h, x.w, x.c + (x2 ? x2->c : 0));
-    if (mode_ == DECLARE) return y;
-    gn_ws_need_ = std::max(gn_ws_need_, sdod_group_norm_workspace_bytes(x.n, 32));
-    if (mode_ != REAL) return y;
-    const void* xp = x.p; const void* x2p = x2 ? x2->p : nullptr; void* yp = y.p;
-    const float* wp = W<float>(gw); const float* bp = W<float>(gb);
-    const int n = x.n, hw = x.h * x.w, c0 = x.c, c1 = x2 ? x2->c : 0, si = silu ? 1 : 0;
-    void* ws = gn_ws_;
-    ops_.push_back(Op{[=](hipStream_t st) {
-        check_rc(sdod_group_norm_nhwc(xp, x2p, yp, wp, bp, n, hw, c0, c1, 32, eps, si, SDOD_F16, ws, st));
-    }, sdod_group_norm_launches(hw, c0 + c1, 32, SDOD_F16) == 1 ? "gn_small" : "gn_stats_apply", 0, 2.0 * n * hw * (c0 + c1) * 2, "n" + std::to_string(n) + " hw" + std::to_string(hw) + " c" + std::to_string(c0 + c1)});
+    Act y = act(x.n, x.h, x.w, x.c + (x2 ? x2->c : 0)); // allocated BEFORE parked tensors return to the arena (see settle())
+    if (mode_ != DECLARE) gn_ws_need_ = std::max(gn_ws_need_, sdod_group_norm_workspace_bytes(x.n, 32));
+    if (mode_ == REAL) {
+        const void* xp = x.p; const void* x2p = x2 ? x2->p : nullptr; void* yp = y.p;
+        const float* wp = W<float>(gw); const float* bp = W<float>(gb);
+        const int n = x.n, hw = x.h * x.w, c0 = x.c, c1 = x2 ? x2->c : 0, si = silu ? 1 : 0;
+        const std::string shape = "n" + std::to_string(n) + " hw" + std::to_string(hw) + " c" + std::to_string(c0 + c1);
+        if (pending_.active && pending_.d.out == x.p && pending_.d.M == x.rows() && pending_.d.N == c0 &&
+            (!pending_.d.row_bias || pending_.d.rows_per_img == hw) && sdod_group_norm_reduce_ok(hw, c0, c1, 32)) {
+            // the producing conv is still in split-K form: this launch also performs its reduce + epilogue
+            sdod_gn_reduce red{};
+            check_rc(sdod_gemm_reduce_info(&pending_.d, &red));
+            pending_.active = false;
+            ops_.push_back(Op{[=](hipStream_t st) {
+                check_rc(sdod_group_norm_reduce_nhwc(&red, x2p, yp, wp, bp, n, hw, c0, c1, 32, eps, si, st));
+            }, "gn_group_red", 0, pending_.bytes + 2.0 * n * hw * (c0 + c1) * 2, shape + " x" + std::to_string(red.splits)});
+        } else {
+            flush_pending();
+            void* ws = gn_ws_;
+            ops_.push_back(Op{[=](hipStream_t st) {
+                check_rc(sdod_group_norm_nhwc(xp, x2p, yp, wp, bp, n, hw, c0, c1, 32, eps, si, SDOD_F16, ws, st));
+            }, sdod_group_norm_launches(hw, c0 + c1, 32, SDOD_F16) == 1 ? "gn_group" : "gn_stats_apply", 0, 2.0 * n * hw * (c0 + c1) * 2, shape});
+        }
+    }
+    drain_parked();
     return y;
 }
 
 Act Graph::layer_norm(const Act& x, int lw, int lb, float eps) {
     Act y = act(x.n, x.h, x.w, x.c);
+    settle();
     if (mode_ != REAL) return y;
     const void* xp = x.p; void* yp = y.p;
     const float* wp = W<float>(lw); const float* bp = W<float>(lb);
@@ -699,6 +728,7 @@ Act Graph::layer_norm(const Act& x, int lw, int lb, float eps) {
 
 void Graph::attention(const f16* q, const f16* k, const f16* v, f16* out, int B, int heads, int lq, int lk, int d, int ldq,
                       int ldk, int ldv, int ldo, bool causal) {
+    settle();
     if (mode_ != REAL) return;
     const double fl = 4.0 * B * heads * (double)lq * lk * d;
     flops_ += fl;
@@ -718,6 +748,7 @@ void Graph::build() {
     case SDOD_GRAPH_TEXT_ENCODER: build_clip(); break;
     default: build_temb(); break;
     }
+    settle();
 }
 
 void Graph::finalize() {

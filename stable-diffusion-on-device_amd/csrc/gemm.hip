@@ -341,6 +341,20 @@ SDOD_DEVICE void wait_younger(int y) {
     else if constexpr (Y > 0) wait_younger<LOADS, Y - 1>(y);
 }
 
+// developer builds only (make lib/libsdod_stamp.so): wall-clock stamps (s_memrealtime, 100 MHz) of the phases of every
+// workgroup -- 0 entry, 1 prologue issued, 2 main loop drained, 3 epilogue tile staged, 4 stores retired -- read back by
+// sdod_gemm_stamps() (tools/gemm_phases.py).  In the product build the macro is empty.
+#ifdef SDOD_GEMM_STAMP
+__device__ unsigned long long g_stamp[8 * 8192];
+#define STAMP(i)                                                                                            \
+    do {                                                                                                    \
+        const unsigned wg_ = blockIdx.x + gridDim.x * blockIdx.z;                                           \
+        if (threadIdx.x == 0 && wg_ < 8192) g_stamp[wg_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime();     \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
 template <int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, const f16* __restrict__ zeros) {
     constexpr int NW = WM * WN;                   // waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD, so one
@@ -367,6 +381,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    STAMP(0);
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int lid = xcd_remap(blockIdx.x, nwg);
@@ -519,6 +534,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
         colv[BN + c] = (ok && p.bias2 != nullptr) ? p.bias2[n] : 0.f;
         colv[2 * BN + c] = (ok && p.ln) ? p.ln_s[n] : 0.f;
     }
+    STAMP(1);
 
     for (int it = 0; it < nkt; ++it) {
         // slab `it` has landed once at most the younger in-flight slabs remain outstanding
@@ -587,6 +603,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
     }
     wait_vmcnt<0>();
     __syncthreads(); // all fragment reads done before the epilogue tile overwrites the ring
+    STAMP(2);
 
     const int e_m = lane & 15;
     const int e_n = (lane >> 4) * 4;
@@ -705,6 +722,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
     }
     }
     __syncthreads();
+    STAMP(3);
 
     const int CPR = p.geglu ? BN / 16 : BN / 8; // 16-byte chunks per output tile row
     const int n_out = p.geglu ? p.N / 2 : p.N;
@@ -733,6 +751,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
             }
         }
     }
+#ifdef SDOD_GEMM_STAMP
+    wait_vmcnt<0>();
+    STAMP(4);
+#endif
 }
 
 // Reduce split-K slabs and apply the fused epilogue.  One thread per 4 consecutive columns.
@@ -908,6 +930,40 @@ extern "C" size_t sdod_gemm_workspace_bytes(const sdod_gemm_desc* d) {
     const Plan pl = make_plan(d);
     return pl.splits > 1 ? (size_t)pl.splits * d->M * d->N * sizeof(float) : 0;
 }
+
+extern "C" int sdod_gemm_reduce_info(const sdod_gemm_desc* d, sdod_gn_reduce* out) {
+    SDOD_TRY
+    SDOD_REQUIRE(d != nullptr && out != nullptr, "null argument");
+    SDOD_REQUIRE(d->K > 0 && d->K % BK == 0, "K must be a multiple of 64");
+    const Plan pl = make_plan(d);
+    SDOD_REQUIRE(pl.splits > 1, "not a split-K plan");
+    SDOD_REQUIRE(!d->bias_on_m && !d->geglu && !d->ln && d->ldo == d->N && d->N % 8 == 0, "epilogue cannot move into a GroupNorm");
+    SDOD_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= (size_t)pl.splits * d->M * d->N * sizeof(float), "split-K workspace missing");
+    out->partial = d->workspace;
+    out->splits = pl.splits;
+    out->slab_floats = (size_t)d->M * d->N;
+    out->bias = d->bias;
+    out->bias2 = d->bias2;
+    out->row_bias = d->row_bias;
+    out->ld_row_bias = d->ld_row_bias > 0 ? d->ld_row_bias : d->N;
+    out->residual = d->residual;
+    out->ldr = d->ldr;
+    out->x_out = d->out;
+    out->alpha = d->alpha;
+    out->act = d->act;
+    out->M = d->M;
+    out->N = d->N;
+    return 0;
+    SDOD_CATCH
+}
+
+#ifdef SDOD_GEMM_STAMP
+extern "C" __attribute__((visibility("default"))) int sdod_gemm_stamps(unsigned long long* out, int n_wg) {
+    if (!out || n_wg <= 0 || n_wg > 8192) return 1;
+    if (hipDeviceSynchronize() != hipSuccess) return 2;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), (size_t)n_wg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 3;
+}
+#endif
 
 extern "C" int sdod_gemm_num_tiles(void) { return kNumTiles; }
 

@@ -216,7 +216,7 @@ void Graph::build_unet() {
         Act t = spatial_transformer("middle_block.1", r1, ctx);
         release(r1);
         Act r2 = res_block("middle_block.2", t, nullptr, ch, emb_all, emb_ld, emb_off);
-        release(t);
+        release_after_consumer(t); // residual of r2's (possibly still split-K) out conv
         h = r2;
     }
     int oidx = 0;
@@ -334,7 +334,7 @@ Act Graph::vae_res_block(const std::string& pfx, const Act& x, int cout) {
     }
     Act out = conv(g2, nullptr, c2w, cout, 3, 1, false, o2);
     release(g2);
-    if (s.p) release(s);
+    if (s.p) release_after_consumer(s);
     return out;
 }
 
@@ -396,14 +396,14 @@ void Graph::build_vae() {
     { GemmOpt o; o.bias = cib; linear(cols, B * H * Wd, 64, ciw, ch, h.p, o); }
     release(cols); release(zl);
 
-    { Act r = vae_res_block("decoder.mid.block_1", h, ch); release(h); h = r; }
+    { Act r = vae_res_block("decoder.mid.block_1", h, ch); release_after_consumer(h); h = r; }
     { Act r = vae_attn_block("decoder.mid.attn_1", h); release(h); h = r; }
-    { Act r = vae_res_block("decoder.mid.block_2", h, ch); release(h); h = r; }
+    { Act r = vae_res_block("decoder.mid.block_2", h, ch); release_after_consumer(h); h = r; }
     for (int level = 3; level >= 0; --level) {
         const int cout = VC * mult[level];
         for (int i = 0; i < 3; ++i) {
             Act r = vae_res_block("decoder.up." + std::to_string(level) + ".block." + std::to_string(i), h, cout);
-            release(h);
+            release_after_consumer(h);
             h = r;
         }
         ch = cout;
@@ -486,6 +486,7 @@ void Graph::build_clip() {
     }
     const int fw = P(oc ? "ln_final.weight" : "text_model.final_layer_norm.weight", {D}, PK_VEC);
     const int fb = P(oc ? "ln_final.bias" : "text_model.final_layer_norm.bias", {D}, PK_VEC);
+    settle();
     if (mode_ == REAL) {
         const f16* xp = x.p; const float* wp = W<float>(fw); const float* bp = W<float>(fb);
         ops_.push_back(Op{[=](hipStream_t st) { check_rc2(sdod_layer_norm_f16(xp, out, wp, bp, rows, D, 1e-5f, st)); }, "layer_norm", 0,

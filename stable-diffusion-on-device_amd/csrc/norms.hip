@@ -61,6 +61,8 @@ struct GnP {
     const float* b;
     float* partial; // [N][nchunks][G][2]
     float* stats;   // [N][G][2] mean, rstd
+    float* shift;   // [N][G] pilot value of every group, written by the statistics pass (the apply pass must not re-read x:
+                    // with y == x another workgroup may already have overwritten pixel 0)
     int N, HW, C0, C1, C, G, Cg;
     float eps;
     int silu;
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnP p) {
         float* dst = p.partial + (((size_t)n * p.nchunks + chunk_id) * p.G + g) * 2;
         dst[0] = a;
         dst[1] = b;
+        if (chunk_id == 0) p.shift[(size_t)n * p.G + g] = (float)*gn_src<T>(p, n, 0, g * p.Cg);
     }
 }
 
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnP p) {
             }
             if (lane == 0) {
                 const float cnt = (float)p.HW * (float)p.Cg;
-                const float shift = (float)*gn_src<T>(p, n, 0, g * p.Cg);
+                const float shift = p.shift[(size_t)n * p.G + g];
                 const float md = a / cnt;
                 float var = b / cnt - md * md;
                 var = var < 0.f ? 0.f : var;
@@ -329,6 +332,288 @@ __global__ __launch_bounds__(NT) void gn_small_kernel(const GnP p, int sw) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// One-launch GroupNorm, a workgroup per (image, group): the form every GroupNorm of the UNet takes (HW <= 4096 at
+// C = 320 / 640, every map of the 32x32 .. 8x8 levels) and the VAE's 64x64 maps.  A group is HW runs of Cg channels
+// (20 .. 160 bytes each); thread t owns vector `t % vpp` of the run (V = 2 / 4 / 8 halves, the widest that divides Cg)
+// for pixels t / vpp, t / vpp + ppp, ..., so its channels -- and their affine parameters -- are fixed, every load is
+// issued before the first use (<= KMAX vectors per thread, held in registers), the statistics are an exact two-pass
+// mean / variance on those registers (two block reductions), and normalise + SiLU + store follow without touching x again.
+// In-place safe: a thread only overwrites what it has read itself.
+//
+// RED = the split-K reduction of the producing conv folded into the load (sdod_gn_reduce): source 0 is still S fp32 partial
+// slabs; x = fp16(act(alpha * sum_s partial + bias + bias2 + row_bias)) + residual, exactly the arithmetic of
+// splitk_reduce_kernel (gemm.hip), is formed in registers, stored to x_out for the tensor's later readers (skip
+// connections, residuals) and normalised in the same pass: one launch instead of three.
+struct GnRed {
+    const float* partial;
+    int splits;
+    size_t slab; // floats per split slab (M * C0)
+    const float* bias;
+    const float* bias2;
+    const f16* row_bias;
+    int ldrb;
+    const f16* residual;
+    int ldr;
+    f16* xout;
+    float alpha;
+    int act;
+};
+struct GnG {
+    const f16* x0;
+    const f16* x1;
+    f16* y;
+    const float* w;
+    const float* b;
+    int HW, C0, C1, C, Cg;
+    float eps;
+    int silu;
+    int vpp, ppp; // vectors per pixel of one group; pixels per pass (= active threads / vpp)
+    GnRed r;
+};
+
+template <int V> struct HalfVec;
+template <> struct HalfVec<2> { typedef f16x2 T; };
+template <> struct HalfVec<4> { typedef f16x4 T; };
+template <> struct HalfVec<8> { typedef f16x8 T; };
+template <int V> struct FloatVec { float v[V]; };
+
+template <int V>
+SDOD_DEVICE FloatVec<V> ldf(const float* p) {
+    FloatVec<V> o;
+    if constexpr (V == 2) {
+        const f32x2 t = *reinterpret_cast<const f32x2*>(p);
+        o.v[0] = t[0]; o.v[1] = t[1];
+    } else {
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+            o.v[4 * q] = t[0]; o.v[4 * q + 1] = t[1]; o.v[4 * q + 2] = t[2]; o.v[4 * q + 3] = t[3];
+        }
+    }
+    return o;
+}
+
+// keeps the PACKED fp16 registers as the live form between the phases (the compiler would otherwise hoist the fp32
+// conversions of all KMAX vectors above the reductions and spill)
+template <typename VT>
+SDOD_DEVICE void pin(VT& v) {
+    asm volatile("" : "+v"(v));
+}
+
+template <int NT>
+SDOD_DEVICE float block_sum(float v, float* red, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) t += red[w];
+    __syncthreads(); // `red` is reused by the next reduction
+    return t;
+}
+
+template <int V, int NT, int KMAX, bool RED>
+__global__ __launch_bounds__(NT) void gn_group_kernel(const GnG p) {
+    typedef typename HalfVec<V>::T VT;
+    __shared__ float red[NT / 64];
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const bool active = tid < p.ppp * p.vpp;
+    const int pix0 = tid / p.vpp;
+    const int c = g * p.Cg + (tid - pix0 * p.vpp) * V; // first of this thread's V channels (concatenated channel space)
+    const bool src1 = c >= p.C0;
+    const size_t row0 = (size_t)n * p.HW;
+    const f16* src = src1 ? p.x1 + row0 * p.C1 + (c - p.C0) : p.x0 + row0 * p.C0 + c;
+    const int sstride = src1 ? p.C1 : p.C0;
+
+    // affine parameters of "my" channels first: their round trip hides behind the loads below
+    float pw[V], pb[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        pw[e] = (active && p.w) ? p.w[c + e] : 1.0f;
+        pb[e] = (active && p.b) ? p.b[c + e] : 0.0f;
+    }
+
+    VT vals[KMAX];
+    if (RED && !src1) {
+        if constexpr (RED) {
+            float acc[KMAX][V];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[k][e] = 0.f;
+            for (int s = 0; s < p.r.splits; ++s) { // ascending, as splitk_reduce_kernel sums
+                const float* ps = p.r.partial + (size_t)s * p.r.slab + row0 * p.C0 + c;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    const int pix = pix0 + k * p.ppp;
+                    if (active && pix < p.HW) {
+                        const FloatVec<V> t = ldf<V>(ps + (size_t)pix * p.C0);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) acc[k][e] += t.v[e];
+                    }
+                }
+            }
+            float b1[V], b2[V], rb[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                b1[e] = (active && p.r.bias) ? p.r.bias[c + e] : 0.f;
+                b2[e] = (active && p.r.bias2) ? p.r.bias2[c + e] : 0.f;
+                rb[e] = (active && p.r.row_bias) ? (float)p.r.row_bias[(size_t)n * p.r.ldrb + c + e] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int pix = pix0 + k * p.ppp;
+                VT h;
+#pragma unroll
+                for (int e = 0; e < V; ++e) h[e] = (f16)0.f;
+                if (active && pix < p.HW) {
+                    VT rs;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) rs[e] = (f16)0.f;
+                    if (p.r.residual) rs = *reinterpret_cast<const VT*>(p.r.residual + (row0 + pix) * p.r.ldr + c);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        float f = acc[k][e] * p.r.alpha;
+                        if (p.r.bias) f += b1[e];
+                        if (p.r.bias2) f += b2[e];
+                        if (p.r.row_bias) f += rb[e];
+                        f = apply_act(f, p.r.act);
+                        f = (float)(f16)f; // same rounding point as the un-split path
+                        if (p.r.residual) f += (float)rs[e];
+                        h[e] = (f16)f;
+                    }
+                    *reinterpret_cast<VT*>(p.r.xout + (row0 + pix) * p.C0 + c) = h;
+                }
+                vals[k] = h;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int pix = pix0 + k * p.ppp;
+            VT h;
+#pragma unroll
+            for (int e = 0; e < V; ++e) h[e] = (f16)0.f;
+            if (active && pix < p.HW) h = *reinterpret_cast<const VT*>(src + (size_t)pix * sstride);
+            vals[k] = h;
+        }
+    }
+
+    // exact two-pass statistics on the registers (invalid slots hold zeros and are excluded from the second pass)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) pin(vals[k]);
+    float s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+        for (int e = 0; e < V; ++e) s1 += (float)vals[k][e];
+    const float inv_cnt = 1.0f / ((float)p.HW * (float)p.Cg);
+    const float mean = block_sum<NT>(s1, red, tid) * inv_cnt;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) pin(vals[k]);
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const bool ok = active && (pix0 + k * p.ppp) < p.HW;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float d = (float)vals[k][e] - mean;
+            s2 += ok ? d * d : 0.f;
+        }
+    }
+    const float var = block_sum<NT>(s2, red, tid) * inv_cnt;
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) pin(vals[k]);
+
+    float sc[V], sh[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        sc[e] = rstd * pw[e];
+        sh[e] = pb[e] - mean * rstd * pw[e];
+    }
+    f16* dst = p.y + row0 * p.C + c;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int pix = pix0 + k * p.ppp;
+        if (active && pix < p.HW) {
+            VT o;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float f = (float)vals[k][e] * sc[e] + sh[e];
+                if (p.silu) f = silu_f(f);
+                o[e] = (f16)f;
+            }
+            *reinterpret_cast<VT*>(dst + (size_t)pix * p.C) = o;
+        }
+    }
+}
+
+// tier of the group kernel for a shape: 0 = not eligible.  id = V * 1000 + (NT == 1024 ? 100 : 0) + KMAX
+struct GroupPlan {
+    int v = 0, nt = 0, kmax = 0, vpp = 0, ppp = 0;
+};
+static GroupPlan gn_group_plan(int hw, int c0, int c1, int cg, bool red) {
+    GroupPlan pl;
+    const int v = cg % 8 == 0 ? 8 : cg % 4 == 0 ? 4 : cg % 2 == 0 ? 2 : 0;
+    if (!v || c0 % 8 || c1 % 8) return pl;
+    const int vpp = cg / v;
+    if (vpp > 256) return pl;
+    int nt = (size_t)hw * vpp <= 512 ? 256 : 1024;
+    int ppp = nt / vpp;
+    int k = (hw + ppp - 1) / ppp;
+    int kmax = 0;
+    if (nt == 256) {
+        if (k <= 2) kmax = 2;
+        else { nt = 1024; ppp = nt / vpp; k = (hw + ppp - 1) / ppp; }
+    }
+    // register budget at 1024 threads (128 VGPRs): the packed vectors may take about 96 of them
+    if (nt == 1024) kmax = k <= 2 ? 2 : k <= 8 ? 8 : (k <= 16 && v == 8) ? 16 : (k <= 24 && v <= 4) ? 24 : (k <= 48 && v == 2) ? 48 : 0;
+    if (!kmax || (red && kmax > 8)) return pl;
+    pl.v = v; pl.nt = nt; pl.kmax = kmax; pl.vpp = vpp; pl.ppp = ppp;
+    return pl;
+}
+
+template <int V, int NT, int KMAX>
+static void gn_group_launch2(const GnG& g, int G, int N, bool red, hipStream_t st) {
+    if constexpr (KMAX <= 8) {
+        if (red) {
+            hipLaunchKernelGGL((gn_group_kernel<V, NT, KMAX, true>), dim3(G, N), dim3(NT), 0, st, g);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((gn_group_kernel<V, NT, KMAX, false>), dim3(G, N), dim3(NT), 0, st, g);
+}
+template <int V>
+static void gn_group_launch1(const GnG& g, const GroupPlan& pl, int G, int N, bool red, hipStream_t st) {
+    if (pl.nt == 256) gn_group_launch2<V, 256, 2>(g, G, N, red, st);
+    else if (pl.kmax == 2) gn_group_launch2<V, 1024, 2>(g, G, N, red, st);
+    else if (pl.kmax == 8) gn_group_launch2<V, 1024, 8>(g, G, N, red, st);
+    else if (pl.kmax == 16) {
+        if constexpr (V == 8) gn_group_launch2<8, 1024, 16>(g, G, N, red, st);
+    } else if (pl.kmax == 24) {
+        if constexpr (V <= 4) gn_group_launch2<V, 1024, 24>(g, G, N, red, st);
+    } else if constexpr (V == 2) gn_group_launch2<2, 1024, 48>(g, G, N, red, st);
+}
+// returns false when the shape is not eligible (the caller falls back to the other paths)
+static bool gn_group_try(const GnP& p, const GnRed* red, hipStream_t st) {
+    const GroupPlan pl = gn_group_plan(p.HW, p.C0, p.C1, p.Cg, red != nullptr);
+    if (!pl.v) return false;
+    GnG g{};
+    g.x0 = (const f16*)p.x0; g.x1 = (const f16*)p.x1; g.y = (f16*)p.y; g.w = p.w; g.b = p.b;
+    g.HW = p.HW; g.C0 = p.C0; g.C1 = p.C1; g.C = p.C; g.Cg = p.Cg; g.eps = p.eps; g.silu = p.silu;
+    g.vpp = pl.vpp; g.ppp = pl.ppp;
+    if (red) g.r = *red;
+    if (pl.v == 8) gn_group_launch1<8>(g, pl, p.G, p.N, red != nullptr, st);
+    else if (pl.v == 4) gn_group_launch1<4>(g, pl, p.G, p.N, red != nullptr, st);
+    else gn_group_launch1<2>(g, pl, p.G, p.N, red != nullptr, st);
+    SDOD_HIP_CHECK(hipGetLastError());
+    return true;
+}
+
 static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 
 // single-launch path eligibility (also what sdod_group_norm_launches reports).  Up to 256 pixels a 256-thread workgroup
@@ -367,6 +652,7 @@ constexpr int GN_INLINE_CHUNKS = 128; // up to here the apply pass reduces the p
 
 template <typename T>
 void gn_launch(GnP& p, hipStream_t st) {
+    if (sizeof(T) == 2 && gn_group_try(p, nullptr, st)) return;
     if (gn_try_small<T>(p, st)) return;
     const int cp = p.C / 8;
     p.npass = (cp + 255) / 256;
@@ -496,12 +782,45 @@ extern "C" int sdod_ln_fold_f16(void* w, int n, int k, int ldw, const float* gam
 
 extern "C" int sdod_group_norm_launches(int hw, int c, int groups, int dtype) {
     if (hw <= 0 || c <= 0 || groups <= 0 || c % groups) return 0;
+    if (dtype == SDOD_F16 && c % 8 == 0 && gn_group_plan(hw, c, 0, c / groups, false).v) return 1;
     return gn_small_fits(hw, c, c / groups, dtype == SDOD_F16 ? 2 : 4) ? 1 : 2; // (+1 collapse launch on very large maps)
+}
+
+extern "C" int sdod_group_norm_reduce_ok(int hw, int c0, int c1, int groups) {
+    if (hw <= 0 || c0 <= 0 || c1 < 0 || groups <= 0 || (c0 + c1) % groups || c0 % 8 || c1 % 8) return 0;
+    return gn_group_plan(hw, c0, c1, (c0 + c1) / groups, true).v ? 1 : 0;
+}
+
+extern "C" int sdod_group_norm_reduce_nhwc(const sdod_gn_reduce* red, const void* x2, void* y, const float* weight,
+                                           const float* bias, int n, int hw, int c0, int c1, int groups, float eps, int silu,
+                                           void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(red && y && red->partial && red->x_out && red->splits > 1, "null pointer / not a split-K descriptor");
+    SDOD_REQUIRE(n > 0 && hw > 0 && c0 > 0 && c1 >= 0 && groups > 0 && (c0 + c1) % groups == 0, "bad shape");
+    SDOD_REQUIRE(c1 == 0 || x2 != nullptr, "c1 > 0 needs x2");
+    SDOD_REQUIRE((weight == nullptr) == (bias == nullptr), "weight and bias must both be given or both be null");
+    SDOD_REQUIRE(red->M == n * hw && red->N == c0 && red->slab_floats == (size_t)red->M * red->N, "reduce descriptor does not match the GroupNorm shape");
+    SDOD_REQUIRE(!red->residual || red->ldr % 8 == 0, "residual row stride must keep 16-byte alignment");
+    SDOD_REQUIRE(!red->row_bias || red->ld_row_bias >= c0, "row_bias stride < c0");
+    SDOD_REQUIRE(sdod_group_norm_reduce_ok(hw, c0, c1, groups), "shape not eligible for the fused reduce (run the GEMM's phase 2 instead)");
+    GnP p{};
+    p.x0 = red->x_out; p.x1 = x2; p.y = y; p.w = weight; p.b = bias;
+    p.N = n; p.HW = hw; p.C0 = c0; p.C1 = c1; p.C = c0 + c1; p.G = groups; p.Cg = (c0 + c1) / groups;
+    p.eps = eps; p.silu = silu;
+    GnRed r{};
+    r.partial = (const float*)red->partial; r.splits = red->splits; r.slab = red->slab_floats;
+    r.bias = (const float*)red->bias; r.bias2 = (const float*)red->bias2;
+    r.row_bias = (const f16*)red->row_bias; r.ldrb = red->ld_row_bias;
+    r.residual = (const f16*)red->residual; r.ldr = red->ldr;
+    r.xout = (f16*)red->x_out; r.alpha = red->alpha; r.act = red->act;
+    SDOD_REQUIRE(gn_group_try(p, &r, (hipStream_t)stream), "shape not eligible");
+    return 0;
+    SDOD_CATCH
 }
 
 extern "C" size_t sdod_group_norm_workspace_bytes(int n, int groups) {
     if (n <= 0 || groups <= 0) return 0;
-    return ((size_t)n * GN_MAX_CHUNKS * groups * 2 + (size_t)n * groups * 2) * sizeof(float);
+    return ((size_t)n * GN_MAX_CHUNKS * groups * 2 + (size_t)n * groups * 3) * sizeof(float);
 }
 
 extern "C" int sdod_group_norm_nhwc(const void* x, const void* x2, void* y, const float* weight, const float* bias, int n,
@@ -532,6 +851,7 @@ extern "C" int sdod_group_norm_nhwc(const void* x, const void* x2, void* y, cons
     p.nchunks = (hw + p.pix_per_chunk - 1) / p.pix_per_chunk;
     p.partial = (float*)workspace;
     p.stats = p.partial + (size_t)n * GN_MAX_CHUNKS * groups * 2;
+    p.shift = p.stats + (size_t)n * groups * 2;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SDOD_F16) gn_launch<f16>(p, st);
     else gn_launch<float>(p, st);

@@ -46,7 +46,7 @@ def workspace(nbytes, device, tag='default'):
 
 def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=None, alpha=1.0, out=None,
          conv=None, a2=None, bias_on_m=False, split_k=0, tile=0, time_iters=0, geglu=False, tail=None, bias2=None,
-         ln_s=None, ln_eps=1e-5, cold_scratch=None):
+         ln_s=None, ln_eps=1e-5, cold_scratch=None, phase=0, return_desc=False):
     """out = act(alpha * A @ W^T + bias + row_bias) + residual.
 
     a: fp16 [M, K] (rows mode) or NHWC [N, H, W, C0] with conv=dict(stride=1|2, upsample=bool) (3x3 pad 1);
@@ -125,8 +125,37 @@ def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=N
         else:
             check(lib.sdod_gemm_time(ctypes.byref(d), _stream(), time_iters, ctypes.byref(ms)))
         return ms.value
+    d.phase = phase           # split-K only: 1 = partial slabs only (a GroupNorm may finish the job, group_norm_reduce)
     check(lib.sdod_gemm_f16(ctypes.byref(d), _stream()))
+    if return_desc:
+        d._keep = (a, w, bias, residual, row_bias, out, a2, bias2)   # the descriptor holds raw pointers
+        return out, d
     return out
+
+
+class GnReduce(ctypes.Structure):
+    """mirror of `struct sdod_gn_reduce`"""
+    _fields_ = [('partial', ctypes.c_void_p), ('splits', ctypes.c_int), ('slab_floats', ctypes.c_size_t), ('bias', ctypes.c_void_p),
+                ('bias2', ctypes.c_void_p), ('row_bias', ctypes.c_void_p), ('ld_row_bias', ctypes.c_int), ('residual', ctypes.c_void_p),
+                ('ldr', ctypes.c_int), ('x_out', ctypes.c_void_p), ('alpha', ctypes.c_float), ('act', ctypes.c_int),
+                ('M', ctypes.c_int), ('N', ctypes.c_int)]
+
+
+def group_norm_reduce(desc, n, hw, groups, weight=None, bias=None, eps=1e-5, silu=False, x2=None):
+    """GroupNorm(+SiLU) of the output of a split-K GEMM launched with phase=1 (desc from gemm(..., return_desc=True)): the
+    reduce + epilogue of that GEMM and the normalisation in one launch.  Returns y; x lands in the GEMM's `out`."""
+    lib = _lib.hip()
+    red = GnReduce()
+    check(lib.sdod_gemm_reduce_info(ctypes.byref(desc), ctypes.byref(red)))
+    c0 = desc.N
+    c1 = x2.shape[-1] if x2 is not None else 0
+    dev = desc._keep[0].device
+    y = torch.empty((n, hw, c0 + c1), dtype=torch.float16, device=dev)
+    if weight is not None:
+        weight = weight.detach().to(torch.float32).contiguous(); bias = bias.detach().to(torch.float32).contiguous()
+    check(lib.sdod_group_norm_reduce_nhwc(ctypes.byref(red), _p(x2), _p(y), _p(weight), _p(bias), n, hw, c0, c1, groups, eps,
+                                          1 if silu else 0, _stream()))
+    return y
 
 
 def group_norm_nhwc(x, groups, weight=None, bias=None, eps=1e-5, silu=False, x2=None, out=None):

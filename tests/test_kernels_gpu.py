@@ -257,6 +257,52 @@ def test_group_norm(n, hw, c, g, dtype, silu):
     check(out, ref, tol=2e-3 if dtype == torch.float16 else 2e-5, name=f'gn {n}x{hw}x{c}')
 
 
+@pytest.mark.parametrize('n,hw_side,cin,cout,c1,split,with_res', [
+    (2, 8, 1280, 1280, 0, 6, True),       # 8x8 level ResBlock out conv (identity skip): V = 8, 256-thread tier
+    (2, 16, 1280, 1280, 640, 6, False),   # feeds a GroupNorm over the concat (h | skip): groups of 60 straddle the boundary
+    (2, 32, 640, 640, 0, 3, True),        # 32x32 level: V = 4, 1024-thread tier, 6 vectors per thread
+    (4, 16, 640, 1280, 0, 5, False),      # batch 4 (config 4), time-embedding row bias
+])
+def test_group_norm_with_fused_splitk_reduce(n, hw_side, cin, cout, c1, split, with_res):
+    """sdod_group_norm_reduce_nhwc == split-K phase 2 followed by the plain GroupNorm, bit for bit (x and y)"""
+    from sdod.amd import ops
+    d = dev()
+    hw = hw_side * hw_side
+    x = rnd((n, hw_side, hw_side, cin), 60).to(d)
+    wt = rnd((cout, 9 * cin), 61, (9 * cin) ** -0.5).to(d)
+    gen = torch.Generator().manual_seed(62)
+    bias = torch.randn(cout, generator=gen).to(d)
+    temb = rnd((n, cout), 63).to(d)
+    res = rnd((n, hw_side, hw_side, cout), 64).to(d) if with_res else None
+    x2 = rnd((n, hw, c1), 65, 2.0).to(d) if c1 else None
+    gw = (1 + 0.1 * torch.randn(cout + c1, generator=gen)).to(d); gb = (0.1 * torch.randn(cout + c1, generator=gen)).to(d)
+    kw = dict(residual=res, row_bias=temb, rows_per_img=hw, conv=dict(stride=1), split_k=split, tile=8)
+    full = ops.gemm(x, wt, bias, **kw).clone()                                      # phases 1 + 2
+    y_ref = ops.group_norm_nhwc(full.reshape(n, hw, cout), 32, gw, gb, 1e-5, True, x2=x2)
+    out, desc = ops.gemm(x, wt, bias, phase=1, return_desc=True, **kw)
+    out.fill_(float('nan'))                                                         # phase 1 must not have written it
+    y = ops.group_norm_reduce(desc, n, hw, 32, gw, gb, 1e-5, True, x2=x2)
+    torch.cuda.synchronize()
+    assert torch.equal(out, full), 'x written by the fused kernel differs from splitk_reduce'
+    assert torch.equal(y, y_ref), 'GroupNorm output differs from the two-launch path'
+    ref = F.silu(F.group_norm(torch.cat([full.reshape(n, hw, cout).float().cpu()] + ([x2.float().cpu()] if c1 else []), -1).permute(0, 2, 1),
+                              32, gw.cpu(), gb.cpu(), 1e-5).permute(0, 2, 1))
+    check(y, ref, name='gn fused reduce')
+
+
+def test_group_norm_in_place_is_safe():
+    """y == x on the two-launch path: the apply pass takes the pilot shift from the workspace, not from x"""
+    from sdod.amd import ops
+    gen = torch.Generator().manual_seed(52)
+    x = (torch.randn(1, 16384, 512, generator=gen) * 2 + 3).half()                 # 16 MB image: statistics + apply launches
+    wt = 1 + 0.1 * torch.randn(512, generator=gen); b = 0.1 * torch.randn(512, generator=gen)
+    ref = F.silu(F.group_norm(x.float().permute(0, 2, 1), 32, wt, b, 1e-6).permute(0, 2, 1))
+    d = dev()
+    xd = x.to(d)
+    out = ops.group_norm_nhwc(xd, 32, wt.to(d), b.to(d), 1e-6, True, out=xd)
+    check(out, ref, name='gn in place')
+
+
 def test_group_norm_concat_sources():
     from sdod.amd import ops
     gen = torch.Generator().manual_seed(51)
