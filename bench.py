@@ -30,6 +30,7 @@ import torch  # noqa: E402
 METRIC = 'images/sec + per-UNet-step ms, SD v1.4 512x512 20-step PLMS, 1/2/4/8 MI355X'
 PEAK_TFLOPS_F16 = 2500.0   # dense fp16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+PMC_SUMMARY = 'r02_pmc_summary.json'   # committed summary of the rocprofv3 --pmc passes of this round's build
 # "a photograph of an astronaut riding a horse" needs the CLIP vocabulary, which is absent offline: fixed ids
 IDS_COND = [49406, 320, 1125, 539, 550, 18376, 6765, 320, 4558] + [49407] * 68
 IDS_UNCOND = [49406] + [49407] * 76
@@ -145,7 +146,7 @@ def main():
             dist.init_process_group(backend)
 
     from sdod.amd import engine as E, ops, weights as Wt
-    from sdod.amd.pipeline import Txt2Img, broadcast_conditioning, initial_latent
+    from sdod.amd.pipeline import Txt2Img, broadcast_conditioning, device_latent, initial_latent
 
     t_setup = time.time()
     torch.set_num_threads(host_threads())
@@ -158,7 +159,7 @@ def main():
     log('uploading weights / building graphs')
     pipe = Txt2Img(state_dicts=sds, images_per_gpu=n, latent_hw=64, device=f'cuda:{dev_index}',
                    use_hip_graph=not args.no_hip_graph, cfg_split=args.cfg_split)
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and (args.sampler, args.sampler_steps) == ('plms', 20)
     if not want_cpu:
         sds = None
     setup_s = time.time() - t_setup
@@ -167,7 +168,13 @@ def main():
     x_T = torch.cat([initial_latent(42, img_owner * n + i) for i in range(n)]).to(device)
     ids_u, ids_c = np.asarray(IDS_UNCOND), np.asarray(IDS_COND)
 
+    n_images_per_step = n * (world // 2 if args.cfg_split else world)
+    step_no = [0]
+
     def one_image():
+        # a fresh x_T per timed image, drawn on the device (Philox keyed by (seed 42, global image index): SURVEY 7.2)
+        k = step_no[0]; step_no[0] += 1
+        x_T = torch.cat([device_latent(42, k * n_images_per_step + img_owner * n + i, device=device) for i in range(n)])
         if rank == 0:
             ctx2 = pipe.encode_tokens(ids_u, ids_c)
         else:
@@ -232,6 +239,18 @@ def main():
         for (label, fl, by), t in zip(table, ms):
             f = fam.setdefault(label, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
             f['ms'] += t; f['flops'] += fl; f['bytes'] += by; f['launches'] += 1
+        # per-shape table (label, shape, launches per evaluation, us each, TF/s, GB/s): printed on stderr and carried in
+        # the JSON line, so BENCH, the rocprofv3 CSV and the PMC passes can be compared shape by shape
+        details = pipe.unet.op_details()
+        shapes = {}
+        for (label, fl, by), det, t in zip(table, details, ms):
+            r = shapes.setdefault((label, det), [0, 0.0, 0.0, 0.0])
+            r[0] += 1; r[1] += t; r[2] += fl; r[3] += by
+        shape_rows = [[lab, det, r[0], round(1e3 * r[1] / r[0], 2), round(r[2] / (r[1] * 1e-3) / 1e12, 1) if r[2] else None,
+                       round(r[3] / (r[1] * 1e-3) / 1e9, 1) if r[3] else None]
+                      for (lab, det), r in sorted(shapes.items(), key=lambda kv: -kv[1][1])]
+        log('UNet launch list by shape (eager, HIP events):\n' + '\n'.join(
+            f'  {lab:16s} {det:44s} x{n:<3d} {us:8.2f} us  {str(tf):>7s} TF/s  {str(gb):>8s} GB/s' for lab, det, n, us, tf, gb in shape_rows))
         dom = max(fam, key=lambda k: fam[k]['ms'])
         d = fam[dom]
         total_ms = sum(ms)
@@ -242,19 +261,22 @@ def main():
         else:
             ach = d['bytes'] / (d['ms'] * 1e-3) / 1e9
             roof = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
-        # HBM bytes per launch of that kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected offline in separate
-        # passes by tools/run_profile.sh, summarised with the guide's gfx950 corrections by tools/pmc_summary.py and committed
-        # under profiles/; null when no measurement matches the dominant symbol)
+        # HBM bytes per launch of that kernel: rocprofv3 PMC passes cannot run inside this process, so the figure comes from
+        # the committed summary of separate `--pmc` passes over the SAME launch list (the shipped tune table fixes the tile
+        # picks, tools/run_profile.sh + tools/pmc_summary.py apply the guide's gfx950 corrections); `traffic_source` says so,
+        # and the fields stay null when no committed measurement matches the dominant symbol
         try:
             import re
             sym = KERNEL_SYMBOLS.get(dom, dom)
             nums = re.findall(r'\d+', sym)
             mangled = ''.join(f'Li{n}E' for n in nums) if sym.startswith('gemm_glds_kernel') else None
-            for k in json.load(open(os.path.join(ROOT, 'profiles', 'r01_d_pmc_summary.json')))['kernels']:
+            pmc_file = os.path.join('profiles', PMC_SUMMARY)
+            for k in json.load(open(os.path.join(ROOT, pmc_file)))['kernels']:
                 name = k['kernel']
                 if (mangled and 'gemm_glds_kernel' in name and ('I' + mangled + 'E') in name) or (not mangled and sym in name):
                     roof['traffic'] = k['hbm_fetch_bytes_per_launch'] + k['hbm_write_bytes_per_launch']
                     roof['mfma_util_pmc'] = k['mfma_util']
+                    roof['traffic_source'] = f'offline: {pmc_file} (separate rocprofv3 --pmc passes, not measured in this run)'
                     break
         except (OSError, ValueError, KeyError, TypeError):
             pass
@@ -262,11 +284,13 @@ def main():
                     flops_per_launch=round(d['flops'] / d['launches']), algorithmic_bytes_per_launch=round(d['bytes'] / d['launches']),
                     launches_per_unet_eval=d['launches'], avg_launch_us=round(1e3 * d['ms'] / d['launches'], 2),
                     share_of_unet_eval=round(d['ms'] / total_ms, 3), unet_eval_eager_ms=round(total_ms, 3),
+                    launches_per_unet_eval_total=len(table), tune_table=pipe.unet.tune_source(),
                     unet_eval_tflops=round(pipe.unet.stats()['flops'] / (unet_step_ms * 1e-3) / 1e12, 1),
                     families={k: dict(ms=round(v['ms'], 3), launches=v['launches'],
                                       tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1) if v['flops'] else None,
                                       gbs=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['bytes'] else None)
-                              for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])})
+                              for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])},
+                    shapes=shape_rows)
 
         value = args.steps * n * (world // 2 if args.cfg_split else world) / elapsed
         out = {
@@ -286,16 +310,21 @@ def main():
         }
 
         if want_cpu:
-            out.update(cpu_baseline_and_parity(pipe, sds, x_T, ctx2, e_gpu=pipe._eps(x_T, temb[0], 7.5, 1)))
+            z_gpu = pipe.sample_plms(ctx2, x_T, steps=20, guidance=7.5)
+            out.update(cpu_baseline_and_parity(pipe, sds, x_T, ctx2, e_gpu=pipe._eps(x_T, temb[0], 7.5, 1),
+                                               img_gpu=pipe.decode(z_gpu, mode=1), z_gpu=z_gpu))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline_and_parity(pipe, sds, x_T, ctx2, e_gpu):
-    """The oracle (CPU fp32 restatement) on the host cores, bounded sample; also the in-run parity number."""
-    from oracle import sd_torch as S
+def cpu_baseline_and_parity(pipe, sds, x_T, ctx2, e_gpu, img_gpu, z_gpu):
+    """The oracle (CPU fp32 restatement, kind "port") on the host cores, as BASELINE.md section 3 prescribes: one warm-up
+    UNet evaluation, ONE timed full image (CLIP encode of both prompts + 20-step PLMS = 21 batch-2 UNet evaluations + VAE
+    decode + uint8) and 3 timed single UNet evaluations; also the in-run parity block (first guided eps, final latent,
+    uint8 image of that very image)."""
+    from oracle import pipeline_oracle as PO, sd_torch as S
     threads = host_threads()
     torch.set_num_threads(threads)
     log(f'cpu baseline: building the oracle ({threads} threads)')
@@ -305,33 +334,42 @@ def cpu_baseline_and_parity(pipe, sds, x_T, ctx2, e_gpu):
     vae.load_state_dict(sds['vae'], assign=True)
     clip.load_state_dict(sds['text'], assign=True)
     unet.eval(); vae.eval(); clip.eval()
-    c16 = ctx2.float().cpu()
+    c16 = ctx2.float().cpu()                      # the oracle consumes the SAME fp16-rounded conditioning the GPU used
     x = x_T[:1].float().cpu()
     t = torch.tensor([951, 951])
+    evals = [0]
+    unet.register_forward_hook(lambda *a: (evals.__setitem__(0, evals[0] + 1), log(f'cpu baseline: UNet evaluation {evals[0]} done'))[0])
     with torch.no_grad():
         x2 = torch.cat([x, x]); c2 = torch.cat([c16[0:1], c16[1:2]])
         t0 = time.perf_counter(); e = unet(x2, t, c2); warm = time.perf_counter() - t0
-        log(f'cpu baseline: first UNet eval {warm:.1f}s')
         times = []
-        for _ in range(2):
+        for _ in range(3):
             t0 = time.perf_counter(); e = unet(x2, t, c2); times.append(time.perf_counter() - t0)
-            log(f'cpu baseline: UNet eval {times[-1]:.1f}s')
         t_unet = float(np.mean(times))
-        t0 = time.perf_counter(); clip(torch.from_numpy(np.stack([IDS_UNCOND, IDS_COND]))); t_clip = time.perf_counter() - t0
-        t0 = time.perf_counter(); vae(torch.randn(1, 4, 64, 64) * 0.18215); t_vae = time.perf_counter() - t0
-        log(f'cpu baseline: CLIP {t_clip:.1f}s, VAE decode {t_vae:.1f}s')
+        log(f'cpu baseline: UNet evaluation {t_unet:.2f}s (first {warm:.2f}s); timing one full image')
+        t0 = time.perf_counter()
+        clip(torch.from_numpy(np.stack([IDS_UNCOND, IDS_COND])))
+        t_clip = time.perf_counter() - t0
+        z_ref = PO.plms_sample(unet, c16[0:1], c16[1:2], x, steps=20, scale=7.5)
+        t_loop = time.perf_counter() - t0 - t_clip
+        img_ref = PO.decode_u8(vae, z_ref, mode=1)
+        t_img = time.perf_counter() - t0
+        log(f'cpu baseline: full image {t_img:.1f}s (CLIP {t_clip:.2f}s, sampler {t_loop:.1f}s, decode {t_img - t_loop - t_clip:.1f}s)')
     e_u, e_c = e.chunk(2)
     e_ref = e_u + 7.5 * (e_c - e_u)
-    eg = e_gpu[:1].float().cpu()
-    rel = float((eg - e_ref).norm() / e_ref.norm())
-    t_img = 21 * t_unet + t_vae + t_clip
+    rel = float(((e_gpu[:1].float().cpu()) - e_ref).norm() / e_ref.norm())
+    zg = z_gpu[:1].float().cpu()
+    rel_z = float((zg.double() - z_ref.double()).norm() / z_ref.double().norm())
+    d = np.abs(img_gpu[:1].cpu().numpy().astype(np.int32) - img_ref.astype(np.int32))
     return {
         'cpu_baseline': {'value': round(1.0 / t_img, 6), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
-                         'unet_step_ms': round(1e3 * t_unet, 1),
-                         'sample': f'PyTorch-CPU fp32 oracle, same weights/inputs: 2 timed UNet evals (batch 2, 4x64x64; mean {t_unet:.2f}s, '
-                                   f'first {warm:.2f}s), 1 VAE decode 64x64->512x512 ({t_vae:.2f}s), 1 CLIP encode ({t_clip:.2f}s); '
-                                   f'image time = 21*t_unet + t_vae + t_clip = {t_img:.1f}s'},
-        'parity': {'guided_eps_rel_l2_gpu_f16_vs_cpu_f32': round(rel, 6), 'tolerance': 1e-2},
+                         'unet_step_ms': round(1e3 * t_unet, 1), 'image_s': round(t_img, 2),
+                         'sample': f'PyTorch-CPU fp32 oracle, same weights/inputs: 1 warm-up UNet evaluation, 3 timed UNet evaluations '
+                                   f'(batch 2, 4x64x64; mean {t_unet:.2f}s), ONE timed full image = CLIP encode x2 ({t_clip:.2f}s) + 20-step PLMS, '
+                                   f'21 UNet evaluations ({t_loop:.1f}s) + VAE decode 64x64->512x512 + uint8 = {t_img:.1f}s'},
+        'parity': {'guided_eps_rel_l2_gpu_f16_vs_cpu_f32': round(rel, 6), 'tolerance': 1e-2,
+                   'final_latent_rel_l2': round(rel_z, 6), 'final_latent_tolerance': 2e-2,
+                   'uint8_image_max_abs_diff': int(d.max()), 'uint8_within_2_lsb': round(float((d <= 2).mean()), 6)},
     }
 
 

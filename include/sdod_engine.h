@@ -97,6 +97,10 @@ SDOD_API int sdod_graph_op_info(void* graph, int index, const char** label, doub
 SDOD_API int sdod_graph_op_detail(void* graph, int index, const char** detail); /* shape string of launch `index` */
 SDOD_API int sdod_graph_profile(void* graph, void* stream, int iters, float* ms_out, int n);
 SDOD_API int sdod_graph_stats(void* graph, size_t* weight_bytes, size_t* arena_bytes, int* num_launches, double* flops);
+/* provenance of the launch list: how many distinct GEMM shapes took their tile from the tune table(s) (the shipped
+ * tune/gfx950.tune, then $SDOD_TUNE_CACHE) and how many were timed in this process (0 = the list is reproducible across
+ * processes); table_path receives the path(s) consulted */
+SDOD_API int sdod_graph_tune_info(void* graph, int* from_table, int* tuned_in_process, char* table_path, int cap);
 
 #ifdef __cplusplus
 }

@@ -178,6 +178,15 @@ SDOD_API int sdod_embedding_f16(const int32_t* ids, const void* table, const voi
 /* context.cpp:257-274: out[i][j]=cos(t_i*f_j), out[i][half+j]=sin(t_i*f_j), f_j=exp(-ln(1e4)*j/half); fp16 out */
 SDOD_API int sdod_timestep_features_f16(const float* t, void* y, int n, int dim, void* stream);
 
+/* Inputs of one guided UNet evaluation in one launch (host loop: context.cpp:348-349): x (fp32, lat_count values = n
+ * images) -> x_dst written `reps` times back to back; temb_row (fp16, temb_width) -> temb_dst, `temb_reps` rows. */
+SDOD_API int sdod_stage_unet_inputs(const float* x, float* x_dst, size_t lat_count, int reps, const void* temb_row,
+                                    void* temb_dst, size_t temb_width, int temb_reps, void* stream);
+/* x_T ~ N(0, I) on the device (replaces the host generator of context.cpp:333-334 for throughput runs): Philox4x32-10
+ * keyed by `seed`, counter (i / 4, stream_id), Box-Muller on the word pairs (0,1), (2,3) with u = ((w >> 8) + 0.5) / 2^24.
+ * words_out (optional, uint32[count]) receives the raw Philox words for bit-exact checks. */
+SDOD_API int sdod_randn_f32(float* out, uint32_t* words_out, size_t count, uint64_t seed, uint64_t stream_id, void* stream);
+
 /* Classifier-free guidance on the batched UNet output.  eps_nhwc: fp16 NHWC [2n][hw][c]; rows [0,n) are the
  * unconditional half when uncond_first != 0 (ldm ordering), else the conditional half.  e_out: fp32 NCHW [n][c][hw].
  *   mode 0: e = g*e_cond + (1-g)*e_uncond         -- the reference driver (context.cpp:359-373, libsdod.h:88)

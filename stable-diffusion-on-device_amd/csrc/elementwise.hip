@@ -295,6 +295,60 @@ __global__ void to_u8_kernel(const f16* img, uint8_t* out, size_t count, float a
 
 } // namespace
 
+
+// ---- sampler-loop staging: the UNet graph's inputs for one guided evaluation in ONE launch.  The latent x (fp32 NCHW, n
+// images) is written `reps` times back to back (uncond rows, then cond rows) and the projected time-conditioning row is
+// broadcast to every batch row -- the three strided copies the host loop used to issue per evaluation.
+__global__ void stage_unet_inputs_kernel(const float* x, float* x_dst, size_t lat, int reps, const f16* temb_row, f16* temb_dst,
+                                         size_t temb_w, int temb_reps) {
+    const size_t nx = lat * (size_t)reps, nt = temb_w * (size_t)temb_reps;
+    GRID_STRIDE(i, nx + nt) {
+        if (i < nx) x_dst[i] = x[i % lat];
+        else temb_dst[i - nx] = temb_row[(i - nx) % temb_w];
+    }
+}
+
+// ---- on-device x_T for throughput runs (SURVEY 7.2 "RNG"): Philox4x32-10 (Salmon et al., SC'11; known-answer vectors in
+// tests/test_kernels_gpu.py via oracle/philox_oracle.py) keyed by `seed`, counter = (block index, stream); the four words
+// of a block give two Box-Muller pairs.  Element i of stream s is a pure function of (seed, s, i): any sharding of the
+// images over ranks draws the same latents.  The reference draws on the host (context.cpp:333-334, std::mt19937).
+SDOD_DEVICE void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+}
+__global__ void randn_kernel(float* out, uint32_t* words, size_t count, uint64_t seed, uint64_t stream) {
+    const size_t nblk = (count + 3) / 4;
+    GRID_STRIDE(j, nblk) {
+        uint32_t c[4] = {(uint32_t)j, (uint32_t)((uint64_t)j >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        float z[4];
+#pragma unroll
+        for (int a = 0; a < 4; a += 2) {
+            const float u1 = ((float)(c[a] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float u2 = ((float)(c[a + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float rad = sqrtf(-2.0f * logf(u1));
+            float sn, cs;
+            sincosf(6.283185307179586f * u2, &sn, &cs);
+            z[a] = rad * cs;
+            z[a + 1] = rad * sn;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (4 * j + q < count) {
+                out[4 * j + q] = z[q];
+                if (words) words[4 * j + q] = c[q];
+            }
+    }
+}
+
 #define LAUNCH(kernel, work, st, ...)                                                            \
     do {                                                                                         \
         hipLaunchKernelGGL(kernel, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)(st), __VA_ARGS__); \
@@ -389,6 +443,25 @@ extern "C" int sdod_softmax_rows_f16(const void* x, void* y, int m, int n, void*
     if (n <= 8192) hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3(m), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, m, n);
     else hipLaunchKernelGGL(softmax_rows_kernel<8>, dim3(m), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, m, n);
     SDOD_HIP_CHECK(hipGetLastError());
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_stage_unet_inputs(const float* x, float* x_dst, size_t lat_count, int reps, const void* temb_row, void* temb_dst,
+                                      size_t temb_width, int temb_reps, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(x && x_dst && lat_count > 0 && reps > 0, "bad latent argument");
+    SDOD_REQUIRE((temb_row && temb_dst && temb_width > 0 && temb_reps > 0) || temb_reps == 0, "bad time-conditioning argument");
+    LAUNCH(stage_unet_inputs_kernel, lat_count * (size_t)reps + temb_width * (size_t)temb_reps, stream, x, x_dst, lat_count, reps,
+           (const f16*)temb_row, (f16*)temb_dst, temb_width, temb_reps);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_randn_f32(float* out, uint32_t* words_out, size_t count, uint64_t seed, uint64_t stream_id, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(out && count > 0, "bad argument");
+    LAUNCH(randn_kernel, (count + 3) / 4, stream, out, words_out, count, seed, stream_id);
     return 0;
     SDOD_CATCH
 }

@@ -133,6 +133,7 @@ private:
     hipGraph_t hip_graph_ = nullptr;
     hipStream_t capture_stream_ = nullptr;
     int eager_runs_ = 0;
+    int tune_hits_ = 0, tune_misses_ = 0;
 
     void build();       // dispatches on kind_
     void build_unet();
@@ -217,6 +218,9 @@ private:
     }
 
 public:
+    // GEMM shapes of this graph whose tile came from the tune table(s) / had to be timed in this process
+    int tune_hits() const { return tune_hits_; }
+    int tune_misses() const { return tune_misses_; }
     int num_ops() const { return (int)ops_.size(); }
     const Op& op(int i) const { return ops_.at(i); }
     // eager run with a HIP event pair around every launch; ms[i] = duration of op i (averaged over `iters` runs)

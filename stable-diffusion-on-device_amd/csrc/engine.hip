@@ -529,6 +529,8 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
         d.workspace_bytes = ws_bytes_;
         const ShapeKey key = key_of(d);
         auto it = tune_cache().find(key);
+        if (it != tune_cache().end()) ++tune_hits_;
+        else ++tune_misses_;
         if (it == tune_cache().end()) {
             int best = 0;
             float best_ms = 1e30f;
@@ -992,6 +994,21 @@ extern "C" int sdod_graph_profile(void* graph, void* stream, int iters, float* m
     SDOD_TRY
     SDOD_REQUIRE(graph != nullptr, "null graph");
     static_cast<Graph*>(graph)->profile((hipStream_t)stream, iters, ms_out, n);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_graph_tune_info(void* graph, int* from_table, int* tuned_in_process, char* table_path, int cap) {
+    SDOD_TRY
+    SDOD_REQUIRE(graph != nullptr, "null graph");
+    auto* g = static_cast<Graph*>(graph);
+    if (from_table) *from_table = g->tune_hits();
+    if (tuned_in_process) *tuned_in_process = g->tune_misses();
+    if (table_path && cap > 0) {
+        std::string s = sdod::shipped_tune_path();
+        if (const char* extra = sdod::tune_cache_path()) s += (s.empty() ? "" : " + ") + std::string(extra);
+        std::snprintf(table_path, (size_t)cap, "%s", s.c_str());
+    }
     return 0;
     SDOD_CATCH
 }

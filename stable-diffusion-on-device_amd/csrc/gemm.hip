@@ -515,25 +515,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) rs1[i] = rs2[i] = 0.f;
 
+    // per-column epilogue vectors (bias, bias2, LayerNorm-fold s) -> LDS by LDS-DMA (4 bytes per lane, no VGPR round trip, no
+    // wait): issued BEFORE the first slab, so they are older than every slab and have landed when the first counted wait of
+    // the main loop returns; the epilogue then has no dependent global loads.  Absent vectors / columns past N read the zero line.
+    constexpr size_t RING_BYTES = (size_t)STAGES * STAGE * sizeof(f16);
+    constexpr size_t CTILE_BYTES = (size_t)BM * SC * sizeof(f16) + (size_t)BM * 2 * sizeof(float);
+    float* colv = reinterpret_cast<float*>(smem_raw + (RING_BYTES > CTILE_BYTES ? RING_BYTES : CTILE_BYTES)); // [3][BN]
+    {
+        constexpr int CHUNKS = (BN + 63) / 64;
+        const float* zf = reinterpret_cast<const float*>(zeros) + lane;
+        for (int job = wave; job < 3 * CHUNKS; job += NW) { // wave-uniform
+            const int vec = job / CHUNKS, q = job - vec * CHUNKS;
+            const int c = q * 64 + lane, n = n0 + c;
+            const float* base = vec == 0 ? ((p.bias != nullptr && !p.bias_on_m) ? p.bias : nullptr) : vec == 1 ? p.bias2 : (p.ln ? p.ln_s : nullptr);
+            const float* g = (base != nullptr && n < p.N) ? base + n : zf;
+            if (c < BN) __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(colv + vec * BN + q * 64), 4, 0, 0);
+        }
+    }
     // prologue: STAGES-1 slabs in flight (issue even past the end -- against the zero line -- so counts stay uniform)
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) {
         if (s < nkt) issue_tile(kt_begin + s, s);
     }
 
-    // per-column epilogue vectors (bias, bias2, LayerNorm-fold s) -> LDS, once per workgroup and coalesced, while the first
-    // slabs are in flight: the epilogue then has no dependent global loads left (they used to be one L2 round trip per
-    // accumulator element).  Columns past N read 0.  Made visible by the barriers of the main loop / before the epilogue.
-    constexpr size_t RING_BYTES = (size_t)STAGES * STAGE * sizeof(f16);
-    constexpr size_t CTILE_BYTES = (size_t)BM * SC * sizeof(f16) + (size_t)BM * 2 * sizeof(float);
-    float* colv = reinterpret_cast<float*>(smem_raw + (RING_BYTES > CTILE_BYTES ? RING_BYTES : CTILE_BYTES)); // [3][BN]
-    for (int c = tid; c < BN; c += NT) {
-        const int n = n0 + c;
-        const bool ok = n < p.N;
-        colv[c] = (ok && p.bias != nullptr && !p.bias_on_m) ? p.bias[n] : 0.f;
-        colv[BN + c] = (ok && p.bias2 != nullptr) ? p.bias2[n] : 0.f;
-        colv[2 * BN + c] = (ok && p.ln) ? p.ln_s[n] : 0.f;
-    }
     STAMP(1);
 
     for (int it = 0; it < nkt; ++it) {
@@ -679,47 +683,113 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
             }
         }
     } else {
+        // Staged as a few short passes over the accumulators instead of one big unrolled body: the common case (bias only)
+        // executes ~10 instructions per accumulator quad; the rare features (LayerNorm fold, per-row bias, per-image row
+        // bias, activation) are wave-uniform branches around their own small loops.  (The one-body form was 25 KB of
+        // straight-line code -- every (i, j) carried all variants -- and cost 3.4 us per workgroup in instruction fetch.)
+        const float alpha = p.alpha;
+        if (p.ln) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int ml = wm * WTM + i * 16 + e_m;
-        const int m = m0 + ml;
-        const f16* rbias = nullptr;
-        if (p.row_bias != nullptr && m < p.M) rbias = p.row_bias + (size_t)(m / p.rows_per_img) * p.ldrb;
+            for (int i = 0; i < TM; ++i) {
+                const int ml = wm * WTM + i * 16 + e_m;
+                const float mean = ln_stats[2 * ml], rstd = ln_stats[2 * ml + 1];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f32x4 sv = *reinterpret_cast<const f32x4*>(colv + 2 * BN + wn * WTN + j * 16 + e_n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = rstd * (acc[i][j][r] * alpha - mean * sv[r]);
+                }
+            }
+        } else if (alpha != 1.0f) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] *= alpha;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nl = wn * WTN + j * 16 + e_n;
-            const int n = n0 + nl;
-            f16x4 h;
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(colv + nl), b2 = *reinterpret_cast<const f32x4*>(colv + BN + nl);
-            const f32x4 sv = *reinterpret_cast<const f32x4*>(colv + 2 * BN + nl);
-            float rb[4] = {0.f, 0.f, 0.f, 0.f};
-            if (rbias != nullptr) {
-                if (n + 3 < p.N && (p.ldrb & 3) == 0 && ((uintptr_t)p.row_bias & 7) == 0) {
-                    const f16x4 t = *reinterpret_cast<const f16x4*>(rbias + n);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) rb[r] = (float)t[r];
-                } else {
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < p.N) rb[r] = (float)rbias[n + r];
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] + b1[r]) + b2[r];
+        }
+        if (p.bias != nullptr && p.bias_on_m) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * WTM + i * 16 + e_m;
+                const float bm = m < p.M ? p.bias[m] : 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += bm;
+            }
+        }
+        if (p.row_bias != nullptr) {
+            const bool rb_vec = (p.ldrb & 3) == 0 && ((uintptr_t)p.row_bias & 7) == 0 && (p.N & 3) == 0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * WTM + i * 16 + e_m;
+                const f16* rbias = p.row_bias + (size_t)((m < p.M ? m : 0) / p.rows_per_img) * p.ldrb;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * WTN + j * 16 + e_n;
+                    if (rb_vec) {
+                        if (n < p.N) {
+                            const f16x4 t = *reinterpret_cast<const f16x4*>(rbias + n);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)t[r];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < p.N) acc[i][j][r] += (float)rbias[n + r];
+                    }
                 }
             }
-            const float mean = p.ln ? ln_stats[2 * ml] : 0.f, rstd = p.ln ? ln_stats[2 * ml + 1] : 1.f;
-            const float bm = (p.bias != nullptr && p.bias_on_m && m < p.M) ? p.bias[m] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[i][j][r] * p.alpha;
-                if (p.ln) v = rstd * (v - mean * sv[r]);
-                v += b1[r];
-                if (p.bias_on_m) v += bm;
-                v += b2[r];
-                if (rbias != nullptr) v += rb[r];
-                v = apply_act(v, p.act);
-                h[r] = (f16)v;
-            }
-            *reinterpret_cast<f16x4*>(sC + ml * SC + nl) = h;
         }
-    }
+        if (p.act != ACT_NONE) {
+#pragma unroll 1
+            for (int pass = 0; pass < 1; ++pass) { // (keeps the three variants out of line with the common path)
+                if (p.act == ACT_SILU) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[i][j][r] = silu_f(acc[i][j][r]);
+                } else if (p.act == ACT_GELU) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_erf_f(acc[i][j][r]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[i][j][r] = quick_gelu_f(acc[i][j][r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int ml = wm * WTM + i * 16 + e_m;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = wn * WTN + j * 16 + e_n;
+                f16x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = (f16)acc[i][j][r];
+                *reinterpret_cast<f16x4*>(sC + ml * SC + nl) = h;
+            }
+        }
     }
     __syncthreads();
     STAMP(3);
@@ -839,8 +909,8 @@ constexpr int kNumTiles = 22;
 const f16* zero_line() {
     static f16* z = nullptr;
     if (!z) {
-        if (hipMalloc((void**)&z, 256) != hipSuccess) return nullptr;
-        (void)hipMemset(z, 0, 256);
+        if (hipMalloc((void**)&z, 1024) != hipSuccess) return nullptr;
+        (void)hipMemset(z, 0, 1024);
     }
     return z;
 }

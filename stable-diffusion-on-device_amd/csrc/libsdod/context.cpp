@@ -52,12 +52,13 @@ Context::~Context() {
 
 void Context::init(unsigned steps) {
     Timer t;
-    SDOD_HIP_CHECK(hipSetDevice(device_));
-    SDOD_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    // host-only pieces first: a models_dir without its files is reported as such even where no device is visible
     tokenizer_.emplace(models_dir_ + "/ctokenizer.txt"); // context.cpp:180-188
     logger_.info("Tokenizer created!");
     solver_.emplace(1000, 0.00085f, 0.0120f);            // context.cpp:191-198
     logger_.info("ODE solver prepared!");
+    SDOD_HIP_CHECK(hipSetDevice(device_));
+    SDOD_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
 
     // context.cpp:94-177: the four graphs.  cond + uncond run as ONE batch-2 UNet evaluation here.
     struct Item { std::unique_ptr<Graph>* slot; int kind; int batch; const char* stem; };
@@ -154,20 +155,19 @@ void Context::generate(const std::string& prompt, float guidance, unsigned char*
 
     for (unsigned step = 0; step < steps_; ++step) {
         t = Timer();
-        // both batch rows see the same latent and time embedding (context.cpp:348-352, :364-366)
-        SDOD_HIP_CHECK(hipMemcpyAsync(ux.ptr, x_dev_, lat * sizeof(float), hipMemcpyDeviceToDevice, stream_));
-        SDOD_HIP_CHECK(hipMemcpyAsync(static_cast<float*>(ux.ptr) + lat, x_dev_, lat * sizeof(float), hipMemcpyDeviceToDevice, stream_));
+        // both batch rows see the same latent and time embedding (context.cpp:348-352, :364-366): one staging launch
         const char* te = reinterpret_cast<const char*>(temb_cache_) + step * temb_row;
-        SDOD_HIP_CHECK(hipMemcpyAsync(ut.ptr, te, temb_row, hipMemcpyDeviceToDevice, stream_));
-        SDOD_HIP_CHECK(hipMemcpyAsync(static_cast<char*>(ut.ptr) + temb_row, te, temb_row, hipMemcpyDeviceToDevice, stream_));
+        rc_check(sdod_stage_unet_inputs(x_dev_, static_cast<float*>(ux.ptr), lat, 2, te, ut.ptr, temb_row / sizeof(f16), 2, stream_));
         unet_->execute(stream_, true, /*skip_static=*/step > 0); // the text context only changes between images
         // e = g*e_cond + (1-g)*e_uncond (context.cpp:359-373); g == 1 keeps e_cond only
         rc_check(sdod_cfg_combine(ue.ptr, e_dev_, 1, C, HW, guidance, /*uncond_first=*/0, /*mode=*/0, stream_));
         const DpmSolver::StepCoef k = solver_->coef(step);
         rc_check(sdod_dpm_update(x_dev_, e_dev_, y_prev_, lat, k.order, k.sigma_s, k.alpha_s, k.sigma_ratio, k.c_prev, k.c_cur, stream_));
-        if ((unsigned)logger_.level() >= (unsigned)LogLevel::INFO) {
+        // the reference logs every iteration at INFO (context.cpp:381) because its host loop waits for the device anyway;
+        // here a per-step synchronisation would stall the launch queue, so only DEBUG (and above) pays for it
+        if ((unsigned)logger_.level() >= (unsigned)LogLevel::DEBUG) {
             SDOD_HIP_CHECK(hipStreamSynchronize(stream_));
-            logger_.info("Single iteration took " + std::to_string((long)t.ms()) + "ms");
+            logger_.debug("Single iteration took " + std::to_string((long)t.ms()) + "ms");
         }
     }
 

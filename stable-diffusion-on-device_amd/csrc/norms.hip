@@ -444,17 +444,32 @@ __global__ __launch_bounds__(NT) void gn_group_kernel(const GnG p) {
             for (int k = 0; k < KMAX; ++k)
 #pragma unroll
                 for (int e = 0; e < V; ++e) acc[k][e] = 0.f;
-            for (int s = 0; s < p.r.splits; ++s) { // ascending, as splitk_reduce_kernel sums
-                const float* ps = p.r.partial + (size_t)s * p.r.slab + row0 * p.C0 + c;
+            // U slabs are requested before the first is summed (a one-slab-at-a-time loop pays a full memory round trip per
+            // split); the sums are still taken in ascending split order, as splitk_reduce_kernel does (+0 for the tail slots)
+            constexpr int U = KMAX * V <= 8 ? 4 : KMAX * V <= 16 ? 2 : 1; // <= 32 staged floats per thread
+            for (int s0 = 0; s0 < p.r.splits; s0 += U) {
+                FloatVec<V> t[U][KMAX];
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) {
-                    const int pix = pix0 + k * p.ppp;
-                    if (active && pix < p.HW) {
-                        const FloatVec<V> t = ldf<V>(ps + (size_t)pix * p.C0);
+                for (int u = 0; u < U; ++u) {
+                    const bool sok = s0 + u < p.r.splits;
+                    const float* ps = p.r.partial + (size_t)(s0 + u) * p.r.slab + row0 * p.C0 + c;
 #pragma unroll
-                        for (int e = 0; e < V; ++e) acc[k][e] += t.v[e];
+                    for (int k = 0; k < KMAX; ++k) {
+                        const int pix = pix0 + k * p.ppp;
+                        if (sok && active && pix < p.HW) {
+                            t[u][k] = ldf<V>(ps + (size_t)pix * p.C0);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) t[u][k].v[e] = 0.f;
+                        }
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                        for (int e = 0; e < V; ++e) acc[k][e] += t[u][k].v[e];
             }
             float b1[V], b2[V], rb[V];
 #pragma unroll
@@ -572,14 +587,14 @@ static GroupPlan gn_group_plan(int hw, int c0, int c1, int cg, bool red) {
     }
     // register budget at 1024 threads (128 VGPRs): the packed vectors may take about 96 of them
     if (nt == 1024) kmax = k <= 2 ? 2 : k <= 8 ? 8 : (k <= 16 && v == 8) ? 16 : (k <= 24 && v <= 4) ? 24 : (k <= 48 && v == 2) ? 48 : 0;
-    if (!kmax || (red && kmax > 8)) return pl;
+    if (!kmax || (red && kmax * v > 32)) return pl; // fused reduce: fp32 sums + one staged slab must fit the register budget
     pl.v = v; pl.nt = nt; pl.kmax = kmax; pl.vpp = vpp; pl.ppp = ppp;
     return pl;
 }
 
 template <int V, int NT, int KMAX>
 static void gn_group_launch2(const GnG& g, int G, int N, bool red, hipStream_t st) {
-    if constexpr (KMAX <= 8) {
+    if constexpr (KMAX * V <= 32) {
         if (red) {
             hipLaunchKernelGGL((gn_group_kernel<V, NT, KMAX, true>), dim3(G, N), dim3(NT), 0, st, g);
             return;

@@ -12,7 +12,8 @@ def load(name):
     """Return the CDLL for lib/<name>; raises ImportError with build instructions if missing."""
     if name in _cache:
         return _cache[name]
-    path = os.path.join(LIB_DIR, name)
+    # SDOD_LIBSDOD=<file in lib/>: developer builds of the same library (sanitizer build: libsdod_asan.so)
+    path = os.path.join(LIB_DIR, os.environ.get('SDOD_LIBSDOD', name) if name == 'libsdod.so' else name)
     if not os.path.exists(path):
         raise ImportError(
             f'{path} not found: build the MI355X extension first '
@@ -85,6 +86,8 @@ def _declare(lib):
         'sdod_latent_prep_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, P]),
         'sdod_embedding_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
         'sdod_timestep_features_f16': (c_int, [P, P, c_int, c_int, P]),
+        'sdod_stage_unet_inputs': (c_int, [P, P, c_size_t, c_int, P, P, c_size_t, c_int, P]),
+        'sdod_randn_f32': (c_int, [P, P, c_size_t, ctypes.c_uint64, ctypes.c_uint64, P]),
         'sdod_cfg_combine': (c_int, [P, P, c_int, c_int, c_int, c_float, c_int, c_int, P]),
         'sdod_dpm_update': (c_int, [P, P, P, c_size_t, c_int, c_float, c_float, c_float, c_float, c_float, P]),
         'sdod_ddim_step_f32': (c_int, [P, P, c_size_t, c_float, c_float, c_float, c_float, P]),
@@ -103,7 +106,7 @@ HIP_SYMBOLS = [
     'sdod_gemm_f16', 'sdod_gemm_workspace_bytes', 'sdod_gemm_plan', 'sdod_gemm_num_tiles', 'sdod_gemm_time', 'sdod_gemm_time_cold', 'sdod_group_norm_workspace_bytes', 'sdod_group_norm_launches', 'sdod_group_norm_nhwc', 'sdod_gemm_reduce_info', 'sdod_group_norm_reduce_ok', 'sdod_group_norm_reduce_nhwc',
     'sdod_layer_norm_f16', 'sdod_ln_fold_f16', 'sdod_attention_f16', 'sdod_softmax_rows_f16', 'sdod_geglu_f16', 'sdod_act_f16',
     'sdod_add_f16', 'sdod_concat_channels_f16', 'sdod_im2col3x3_small_f16', 'sdod_nchw_f32_to_nhwc_f16',
-    'sdod_nhwc_f16_to_nchw_f32', 'sdod_latent_prep_f16', 'sdod_embedding_f16', 'sdod_timestep_features_f16', 'sdod_cfg_combine',
+    'sdod_nhwc_f16_to_nchw_f32', 'sdod_latent_prep_f16', 'sdod_embedding_f16', 'sdod_timestep_features_f16', 'sdod_cfg_combine', 'sdod_stage_unet_inputs', 'sdod_randn_f32',
     'sdod_dpm_update', 'sdod_ddim_step_f32', 'sdod_lincomb4_f32', 'sdod_image_to_u8', 'sdod_hip_last_error',
     'sdod_hip_device_info',
 ]

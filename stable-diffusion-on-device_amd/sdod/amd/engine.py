@@ -22,7 +22,7 @@ class ModelConfig(ctypes.Structure):
 ENGINE_SYMBOLS = [
     'sdod_model_config_sd14', 'sdod_model_config_sd21', 'sdod_graph_create', 'sdod_graph_destroy', 'sdod_graph_num_params', 'sdod_graph_param_info',
     'sdod_graph_set_param', 'sdod_graph_load_file', 'sdod_graph_finalize', 'sdod_graph_io', 'sdod_graph_execute',
-    'sdod_graph_stats', 'sdod_graph_num_ops', 'sdod_graph_op_info', 'sdod_graph_op_detail', 'sdod_graph_profile',
+    'sdod_graph_stats', 'sdod_graph_tune_info', 'sdod_graph_num_ops', 'sdod_graph_op_info', 'sdod_graph_op_detail', 'sdod_graph_profile',
 ]
 
 
@@ -45,6 +45,7 @@ def _engine():
         lib.sdod_graph_execute.argtypes = [P, P, I]
         lib.sdod_graph_stats.argtypes = [P, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(I),
                                          ctypes.POINTER(ctypes.c_double)]
+        lib.sdod_graph_tune_info.argtypes = [P, ctypes.POINTER(I), ctypes.POINTER(I), ctypes.c_char_p, I]
         lib.sdod_graph_num_ops.argtypes = [P]
         lib.sdod_graph_op_info.argtypes = [P, I, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         lib.sdod_graph_profile.argtypes = [P, P, I, P, I]
@@ -184,6 +185,14 @@ class Graph:
         ms = (ctypes.c_float * n)()
         check(self._lib.sdod_graph_profile(self._h, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), iters, ms, n))
         return list(ms)
+
+    def tune_source(self):
+        """where this graph's GEMM tiles came from: table file(s), shapes found there, shapes timed in this process"""
+        a = ctypes.c_int(); b = ctypes.c_int(); buf = ctypes.create_string_buffer(1024)
+        check(self._lib.sdod_graph_tune_info(self._h, ctypes.byref(a), ctypes.byref(b), buf, 1024))
+        import os
+        return {'table': ' + '.join(os.path.basename(p) for p in buf.value.decode().split(' + ') if p), 'shapes_from_table': a.value,
+                'shapes_tuned_in_process': b.value}
 
     def stats(self):
         w = ctypes.c_size_t(); a = ctypes.c_size_t(); n = ctypes.c_int(); f = ctypes.c_double()

@@ -339,6 +339,26 @@ def cfg_combine(eps_nhwc, guidance, uncond_first=True, mode=1):
     return out
 
 
+def stage_unet_inputs(x, x_dst, temb_row, temb_dst):
+    """x fp32 [n,...] -> x_dst [reps*n,...] (repeated back to back); temb_row fp16 [w] -> every row of temb_dst [b, w]"""
+    lib = _lib.hip()
+    _req(x, torch.float32, 'x'); _req(x_dst, torch.float32, 'x_dst'); _req(temb_row, torch.float16, 'temb_row'); _req(temb_dst, torch.float16, 'temb_dst')
+    reps = x_dst.numel() // x.numel()
+    assert reps * x.numel() == x_dst.numel() and temb_dst.numel() % temb_row.numel() == 0
+    check(lib.sdod_stage_unet_inputs(_p(x), _p(x_dst), x.numel(), reps, _p(temb_row), _p(temb_dst), temb_row.numel(),
+                                     temb_dst.numel() // temb_row.numel(), _stream()))
+
+
+def randn(shape, seed, stream_id, device, return_words=False):
+    """N(0,1) fp32 tensor from the in-tree Philox4x32-10 generator: a pure function of (seed, stream_id, element index)"""
+    lib = _lib.hip()
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    words = torch.empty(out.numel(), dtype=torch.int32, device=device) if return_words else None
+    with torch.cuda.device(out.device):
+        check(lib.sdod_randn_f32(_p(out), _p(words), out.numel(), int(seed) & (2 ** 64 - 1), int(stream_id) & (2 ** 64 - 1), _stream()))
+    return (out, words) if return_words else out
+
+
 def dpm_update(x, eps, y_prev, order, sigma_s, alpha_s, sigma_ratio, c_prev, c_cur):
     lib = _lib.hip()
     for t in (x, eps, y_prev):

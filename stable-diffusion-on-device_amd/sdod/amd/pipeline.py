@@ -127,13 +127,8 @@ class Txt2Img:
     def _eps(self, x, temb_row, guidance, mode, v_coef=None):
         """x: fp32 [n,4,H,W]; returns guided eps fp32 [n,4,H,W].  Batch rows: [uncond x n ; cond x n] (ldm order).
         v_coef = (sqrt(abar_t), sqrt(1 - abar_t)) for a v-prediction model: the guided output is v, eps follows from it."""
-        n = self.n
-        if self.cfg_split:
-            self.unet.x.copy_(x)
-            self.unet.temb.copy_(temb_row.unsqueeze(0).expand(n, -1))
-        else:
-            self.unet.x[:n].copy_(x); self.unet.x[n:].copy_(x)
-            self.unet.temb.copy_(temb_row.unsqueeze(0).expand(2 * n, -1))
+        # one in-tree launch stages the graph inputs: x repeated for the (uncond, cond) halves, the time row for every batch row
+        ops.stage_unet_inputs(x, self.unet.x, temb_row, self.unet.temb)
         self.unet.execute(self.use_hip_graph, static_unchanged=not self._ctx_fresh)
         self._ctx_fresh = False
         eps = self._exchange_halves(self.unet.eps) if self.cfg_split else self.unet.eps
@@ -248,3 +243,10 @@ def initial_latent(seed, image_index, shape=(4, 64, 64)):
     """x_T for image `image_index`: CPU generator seeded with (seed, index) so any sharding yields the same images"""
     g = torch.Generator().manual_seed(int(seed) * 1000003 + int(image_index))
     return torch.randn((1,) + tuple(shape), generator=g)
+
+
+def device_latent(seed, image_index, shape=(4, 64, 64), device='cuda:0'):
+    """x_T drawn ON the device for throughput runs (SURVEY 7.2 "RNG"; the reference draws on the host, context.cpp:333-334):
+    in-tree Philox4x32-10 + Box-Muller, stream = image index, so the latent depends on (seed, image index) only -- any
+    sharding of the images over ranks, and any batch slot, yields the same image.  Parity runs inject x_T instead."""
+    return ops.randn((1,) + tuple(shape), seed, image_index, torch.device(device))

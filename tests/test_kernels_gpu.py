@@ -466,6 +466,38 @@ def test_sampler_kernels_bit_exact_vs_oracle(oracle_lib, golden_dir):
     assert np.array_equal(out.reshape(-1).view(np.uint32), ref.reshape(-1).view(np.uint32))
 
 
+def test_device_rng_philox_words_bit_exact_and_normals_vs_oracle():
+    """sdod_randn_f32: the Philox4x32-10 words are bit-exact against the numpy restatement (itself pinned by the published
+    known-answer vectors, tests/test_oracle_host.py); the normals match a float64 Box-Muller of the same words to fp32
+    rounding; the stream is a pure function of (seed, stream id, index)."""
+    from oracle import philox_oracle as PH
+    from sdod.amd import ops
+    d = dev()
+    for seed, stream, count in ((42, 0, 16384), (42, 7, 16384), (2 ** 40 + 12345, 2 ** 33 + 5, 1001)):
+        z, w = ops.randn((count,), seed, stream, d, return_words=True)
+        w_ref, z_ref = PH.randn(count, seed, stream)
+        assert np.array_equal(w.cpu().numpy().view(np.uint32), w_ref.reshape(-1)[:count])          # integer part: bit-exact
+        zc = z.cpu().numpy().astype(np.float64)
+        assert np.isfinite(zc).all() and np.abs(zc - z_ref).max() <= 2e-5 * max(1.0, np.abs(z_ref).max())
+    z = ops.randn((1, 4, 64, 64), 42, 3, d)
+    assert torch.equal(z, ops.randn((1, 4, 64, 64), 42, 3, d))
+    assert torch.equal(z.flatten()[:4096], ops.randn((4096,), 42, 3, d))                          # prefix-stable: index-keyed
+    assert not torch.equal(z, ops.randn((1, 4, 64, 64), 42, 4, d)) and not torch.equal(z, ops.randn((1, 4, 64, 64), 43, 3, d))
+    big = ops.randn((1 << 20,), 1, 0, d).double()
+    assert abs(float(big.mean())) < 5e-3 and abs(float(big.var()) - 1.0) < 5e-3 and abs(float((big ** 4).mean()) - 3.0) < 5e-2
+
+
+def test_stage_unet_inputs_matches_the_copies_it_replaces():
+    from sdod.amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(95)
+    x = torch.randn(2, 4, 16, 16, generator=g).to(d)
+    temb = torch.randn(3, 20160, generator=g).half().to(d)
+    x_dst = torch.full((4, 4, 16, 16), float('nan'), device=d); t_dst = torch.full((4, 20160), float('nan'), dtype=torch.float16, device=d)
+    ops.stage_unet_inputs(x, x_dst, temb[1], t_dst)
+    assert torch.equal(x_dst[:2], x) and torch.equal(x_dst[2:], x) and torch.equal(t_dst, temb[1].unsqueeze(0).expand(4, -1))
+
+
 def test_image_to_u8_vs_oracle(oracle_lib):
     from sdod.amd import ops
     rng = np.random.default_rng(4)

@@ -120,3 +120,20 @@ def test_oracle_clip_agrees_with_transformers_implementation():
     ids = torch.randint(0, 1000, (2, 77), generator=torch.Generator().manual_seed(1))
     with torch.no_grad():
         assert float((c(ids) - hf(input_ids=ids).last_hidden_state).abs().max()) < 1e-4
+
+
+def test_philox_oracle_matches_published_known_answer_vectors():
+    """oracle/philox_oracle.py (the checker of sdod_randn_f32) against the Philox4x32-10 known-answer vectors distributed
+    with the algorithm's reference implementation (Random123 `kat_vectors`: zero, all-ones and the pi-digits inputs)."""
+    import numpy as np
+    from oracle.philox_oracle import philox4x32_10, randn
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        got = philox4x32_10(np.array([ctr], np.uint32), np.array([key], np.uint32))[0]
+        assert [int(v) for v in got] == want
+    w, z = randn(10, 0, 0)                       # counter (0, 0): the first block is the zero-input vector above
+    assert [int(v) for v in w[0]] == kat[0][2] and z.shape == (10,) and np.isfinite(z).all()
+    _, big = randn(1 << 18, 7, 1)
+    assert abs(big.mean()) < 1e-2 and abs(big.var() - 1.0) < 1e-2
