@@ -69,8 +69,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
     const int wave = tid >> 6;
     const int g = lane >> 4;   // lane group 0..3
     const int li = lane & 15;  // index inside the group
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q_block = blockIdx.x * (64 * QT);
+    // 1-D grid, XCD-aware: workgroups b and b + 8 share an XCD and its L2 (round-robin dispatch; speed only), so each XCD is
+    // handed a contiguous run of logical ids, and the query blocks of one (batch, head) are consecutive ids: the K/V of a
+    // head (655 KB at L = 4096, d = 40) is then streamed through ONE L2 instead of all eight (16 heads x 655 KB would thrash
+    // every 4 MiB L2 and every K/V tile load would pay the Infinity-Cache round trip)
+    const int nqb = (p.Lq + 64 * QT - 1) / (64 * QT);
+    const int lid = xcd_remap(blockIdx.x, nqb * p.H * p.B);
+    const int bh = lid / nqb;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q_block = (lid - bh * nqb) * (64 * QT);
 
     const f16* kbase = p.k + (size_t)b * p.Lk * p.ldk + h * D;
     const f16* vbase = p.v + (size_t)b * p.Lk * p.ldv + h * D;
@@ -318,7 +325,7 @@ hipError_t attn_launch(const AttnP& p, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid((p.Lq + 64 * QT - 1) / (64 * QT), p.H, p.B);
+    dim3 grid(((p.Lq + 64 * QT - 1) / (64 * QT)) * p.H * p.B);
     hipLaunchKernelGGL((attn_kernel<D, QT, TR>), grid, dim3(256), smem, st, p);
     return hipGetLastError();
 }

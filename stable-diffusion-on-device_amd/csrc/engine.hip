@@ -416,7 +416,7 @@ IoSlot Graph::io(bool output, int index) const {
 // launch meets inside a replay: the UNet's weights are 1.7 GB, the Infinity Cache 256 MiB.  SDOD_AUTOTUNE=0 disables the
 // tuner (gemm.hip's static heuristic decides), SDOD_AUTOTUNE=hot ranks with back-to-back launches instead.
 namespace {
-const int kCandidates[] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22};
+const int kCandidates[] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 20, 21, 22, 23, 24, 27, 28, 29, 30, 31}; // (16, 25, 26: 128 accumulator registers spill)
 
 struct ShapeKey {
     int v[12];

@@ -355,18 +355,25 @@ __device__ unsigned long long g_stamp[8 * 8192];
 #define STAMP(i)
 #endif
 
-template <int BM, int BN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, const f16* __restrict__ zeros) {
-    constexpr int NW = WM * WN;                   // waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD, so one
-                                                  // wave's DMA issue / LDS reads overlap its partner's MFMAs)
+// SPEC = wave specialisation: the workgroup is WM*WN CONSUMER waves (one per SIMD: fragment reads + MFMA, each owning a
+// (BM/WM)x(BN/WN) output tile) plus as many LOADER waves (their SIMD partners: nothing but the LDS-DMA issue of the slab
+// STAGES-1 ahead, and the LayerNorm-fold row statistics).  In the unspecialised form every wave does reads -> DMA issue ->
+// MFMA in series and the one barrier per slab keeps all waves in lockstep, so per slab the LDS read burst (~0.18 us at
+// 128x128), the DMA issue (~100-180 cycles per instruction, ~0.2 us) and the MFMA cluster (~0.24 us) ADD UP (0.70 us
+// measured, tools/gemm_phases.py); with the roles split they overlap between the same barriers.
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPEC = false>
+__global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kernel(const GemmP p, const f16* __restrict__ zeros) {
+    constexpr int NC = WM * WN;                   // waves that own output tiles
+    constexpr int NW = SPEC ? 2 * NC : NC;        // waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD)
+    constexpr int NL = SPEC ? NC : NW;            // waves that issue the DMA
     constexpr int NT = 64 * NW;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int A_LD = BM / (8 * NW), B_LD = BN / (8 * NW); // DMA instructions per wave per slab (8 rows each)
+    constexpr int A_LD = BM / (8 * NL), B_LD = BN / (8 * NL); // DMA instructions per loading wave per slab (8 rows each)
     constexpr int LOADS = A_LD + B_LD;
     constexpr int STAGE = (BM + BN) * 64;         // halves per slab
     constexpr int SC = BN + 8;
-    static_assert((NW == 4 || NW == 8) && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && TM >= 1 && TN >= 1, "tile shape");
+    static_assert((NW == 4 || NW == 8) && BM % (8 * NL) == 0 && BN % (8 * NL) == 0 && TM >= 1 && TN >= 1, "tile shape");
     static_assert(LOADS * (STAGES - 1) < 64, "vmcnt is a 6-bit counter");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -380,7 +387,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+    const bool is_consumer = !SPEC || wave < NC;                                  // wave-uniform role
+    const int lw = SPEC ? (wave >= NC ? wave - NC : wave) : wave;                 // index among the loading waves
+    const int cw = SPEC ? (wave >= NC ? wave - NC : wave) : wave;                 // index among the consuming waves
+    const int wm = cw / WN, wn = cw % WN;
     STAMP(0);
 
     const int nwg = p.tiles_m * p.tiles_n;
@@ -409,39 +419,41 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
     // Every slab then costs one scalar delta + a handful of VALU per DMA instruction (no divisions, no branches).
     int a_ro0[A_LD], a_ro1[A_LD], a_py[A_LD], a_px[A_LD], a_im[A_LD];
     unsigned a_mask[A_LD];
+    const f16* b_row[B_LD];
     const int pad = p.ksize >> 1;
     const int hup = p.h_in << p.ups, wup = p.w_in << p.ups;
+    auto setup_rows = [&]() {
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-        const int m = m0 + (i * NW + wave) * 8 + lrow;
-        const bool row_ok = m < p.M;
-        const int hw = p.h_out * p.w_out;
-        const int mm = row_ok ? m : 0;
-        const int img = fast_div(mm, p.mg_hw, p.sh_hw);
-        const int rem = mm - img * hw;
-        const int oy = fast_div(rem, p.mg_w, p.sh_w);
-        const int py = oy * p.stride - pad, px = (rem - oy * p.w_out) * p.stride - pad;
-        a_py[i] = py; a_px[i] = px; a_im[i] = img * p.h_in;
-        const int pix = (img * p.h_in + py) * p.w_in + px;
-        a_ro0[i] = pix * p.sa0 + lchunk * 8;
-        a_ro1[i] = pix * p.sa1 + lchunk * 8;
-        unsigned mask = 0;
+        for (int i = 0; i < A_LD; ++i) {
+            const int m = m0 + (i * NL + lw) * 8 + lrow;
+            const bool row_ok = m < p.M;
+            const int hw = p.h_out * p.w_out;
+            const int mm = row_ok ? m : 0;
+            const int img = fast_div(mm, p.mg_hw, p.sh_hw);
+            const int rem = mm - img * hw;
+            const int oy = fast_div(rem, p.mg_w, p.sh_w);
+            const int py = oy * p.stride - pad, px = (rem - oy * p.w_out) * p.stride - pad;
+            a_py[i] = py; a_px[i] = px; a_im[i] = img * p.h_in;
+            const int pix = (img * p.h_in + py) * p.w_in + px;
+            a_ro0[i] = pix * p.sa0 + lchunk * 8;
+            a_ro1[i] = pix * p.sa1 + lchunk * 8;
+            unsigned mask = 0;
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int sx = 0; sx < 3; ++sx) {
-                const bool ok = row_ok & (r < p.ksize) & (sx < p.ksize) & ((unsigned)(py + r) < (unsigned)hup) &
-                                ((unsigned)(px + sx) < (unsigned)wup);
-                mask |= (ok ? 1u : 0u) << (r * p.ksize + sx);
-            }
-        a_mask[i] = mask;
-    }
-    const f16* b_row[B_LD];
-#pragma unroll
-    for (int i = 0; i < B_LD; ++i) {
-        const int n = n0 + (i * NW + wave) * 8 + lrow;
-        b_row[i] = n < p.N ? p.w + (size_t)n * p.ldw + lchunk * 8 : zeros;
-    }
+                for (int sx = 0; sx < 3; ++sx) {
+                    const bool ok = row_ok & (r < p.ksize) & (sx < p.ksize) & ((unsigned)(py + r) < (unsigned)hup) &
+                                    ((unsigned)(px + sx) < (unsigned)wup);
+                    mask |= (ok ? 1u : 0u) << (r * p.ksize + sx);
+                }
+            a_mask[i] = mask;
+        }
+    #pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int n = n0 + (i * NL + lw) * 8 + lrow;
+            b_row[i] = n < p.N ? p.w + (size_t)n * p.ldw + lchunk * 8 : zeros;
+        }
+    };
     const int cin = p.c0 + p.c1;
 
     auto issue_tile = [&](int kt, int stage) {
@@ -461,12 +473,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
                 const int ro = ((a_im[i] + a_py[i] + pad) * p.w_in + a_px[i] + pad) * sa + ccs + lchunk * 8;
                 const bool ok = (a_mask[i] >> centre) & 1u;
                 const f16* g = ok ? src + ro : zeros;
-                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sA + (i * NW + wave) * 8 * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sA + (i * NL + lw) * 8 * 64), 16, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < B_LD; ++i) {
                 const f16* g = b_row[i] + (b_row[i] == zeros ? 0 : k0);
-                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * NW + wave) * 8 * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * NL + lw) * 8 * 64), 16, 0, 0);
             }
             return;
         }
@@ -484,7 +496,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
                 const int ro = (second ? a_ro1[i] : a_ro0[i]) + sdelta;
                 const bool ok = (a_mask[i] >> tap) & 1u;
                 const f16* g = ok ? src + ro : zeros;
-                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sA + (i * NW + wave) * 8 * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sA + (i * NL + lw) * 8 * 64), 16, 0, 0);
             }
         } else {
 #pragma unroll
@@ -493,27 +505,55 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
                 const int ro = ((a_im[i] + yy) * p.w_in + xx) * sa + ccs + lchunk * 8;
                 const bool ok = (a_mask[i] >> tap) & 1u;
                 const f16* g = ok ? src + ro : zeros;
-                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sA + (i * NW + wave) * 8 * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sA + (i * NL + lw) * 8 * 64), 16, 0, 0);
             }
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
             const f16* g = b_row[i] + (b_row[i] == zeros ? 0 : k0);
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * NW + wave) * 8 * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * NL + lw) * 8 * 64), 16, 0, 0);
         }
     };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frag_row = lane & 15;
     const int frag_chunk = lane >> 4;
     float rs1[A_LD], rs2[A_LD]; // LayerNorm fold: this lane's share of sum(x), sum(x^2) of the rows it DMA-ed
+    auto ln_accumulate = [&](const f16* sA) {
+            // every lane re-reads the 16 bytes it DMA-ed into this slab (lane-linear image: conflict-free) -- all of
+            // the row's K columns pass through here, so the row statistics cost one extra LDS read per slab
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) rs1[i] = rs2[i] = 0.f;
+            for (int i = 0; i < A_LD; ++i) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(sA + (i * NL + lw) * 8 * 64 + lane * 8);
+                const f16x2 one2 = {(f16)1.0f, (f16)1.0f};
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) { // v_dot2_f32_f16: two products + fp32 accumulate per instruction
+                    const f16x2 pr = {v[e], v[e + 1]};
+                    rs1[i] = __builtin_amdgcn_fdot2(pr, one2, rs1[i], false);
+                    rs2[i] = __builtin_amdgcn_fdot2(pr, pr, rs2[i], false);
+                }
+            }
+    };
+    constexpr int SC_ = BN + 8;
+    float* ln_stats = reinterpret_cast<float*>(smem_raw + (size_t)BM * SC_ * sizeof(f16)); // [BM][2] mean, rstd
+    auto ln_finalize = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            float a1 = rs1[i], a2 = rs2[i];
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                a1 += __shfl_xor(a1, o);
+                a2 += __shfl_xor(a2, o);
+            }
+            if ((lane & 7) == 0) {
+                const float mean = a1 / (float)p.K;
+                float var = a2 / (float)p.K - mean * mean;
+                var = var < 0.f ? 0.f : var;
+                const int r = (i * NL + lw) * 8 + lrow;
+                ln_stats[2 * r] = mean;
+                ln_stats[2 * r + 1] = 1.0f / sqrtf(var + p.ln_eps);
+            }
+        }
+    };
 
     // per-column epilogue vectors (bias, bias2, LayerNorm-fold s) -> LDS by LDS-DMA (4 bytes per lane, no VGPR round trip, no
     // wait): issued BEFORE the first slab, so they are older than every slab and have landed when the first counted wait of
@@ -532,25 +572,108 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
             if (c < BN) __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(colv + vec * BN + q * 64), 4, 0, 0);
         }
     }
-    // prologue: STAGES-1 slabs in flight (issue even past the end -- against the zero line -- so counts stay uniform)
+    const int e_m = lane & 15;
+    const int e_n = (lane >> 4) * 4;
+    f16* sC = smem;
+    auto store_phase = [&]() {
+    const int CPR = p.geglu ? BN / 16 : BN / 8; // 16-byte chunks per output tile row
+        const int n_out = p.geglu ? p.N / 2 : p.N;
+        const int n0_out = p.geglu ? n0 / 2 : n0;
+        const bool vec_ok = (n_out % 8 == 0) && (p.ldo % 8 == 0) && (p.residual == nullptr || p.ldr % 8 == 0);
+        for (int idx = tid; idx < BM * CPR; idx += NT) {
+            const int row = idx / CPR;
+            const int ch = idx - row * CPR;
+            const int m = m0 + row, n = n0_out + ch * 8;
+            if (m >= p.M || n >= n_out) continue;
+            f16x8 v = *reinterpret_cast<const f16x8*>(sC + row * SC + ch * 8);
+            if (vec_ok) {
+                if (p.residual != nullptr) {
+                    const f16x8 rr = ldg8(p.residual + (size_t)m * p.ldr + n);
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s) {
-        if (s < nkt) issue_tile(kt_begin + s, s);
+                    for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)rr[e]);
+                }
+                stg8(p.out + (size_t)m * p.ldo + n, v);
+            } else {
+                for (int e = 0; e < 8; ++e) {
+                    if (n + e < n_out) {
+                        float f = (float)v[e];
+                        if (p.residual != nullptr) f += (float)p.residual[(size_t)m * p.ldr + n + e];
+                        p.out[(size_t)m * p.ldo + n + e] = (f16)f;
+                    }
+                }
+            }
+        }
+    };
+
+    if constexpr (SPEC) {
+        if (!is_consumer) {
+            // ---------------- LOADER program (complete; shares only the barriers with the consumers) ----------------
+            setup_rows();
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) rs1[i] = rs2[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < STAGES - 1; ++s)
+                if (s < nkt) issue_tile(kt_begin + s, s);
+            STAMP(1);
+            for (int it = 0; it < nkt; ++it) {
+                wait_younger<LOADS, STAGES - 2>(nkt - 1 - it); // slab `it` of THIS wave has landed ...
+                __builtin_amdgcn_s_barrier();                  // ... and everybody's; slab it-1 is no longer read
+                if (p.ln) ln_accumulate(smem + (it % STAGES) * STAGE);
+                if (it + STAGES - 1 < nkt) issue_tile(kt_begin + it + STAGES - 1, (it + STAGES - 1) % STAGES);
+            }
+            wait_vmcnt<0>();
+            __syncthreads();
+            STAMP(2);
+            if (p.ln) {
+                ln_finalize();
+                __syncthreads();
+            }
+            if (p.splits > 1) return;
+            __syncthreads(); // the consumers have staged the output tile
+            STAMP(3);
+            store_phase();
+#ifdef SDOD_GEMM_STAMP
+            wait_vmcnt<0>();
+            STAMP(4);
+#endif
+            return;
+        }
     }
 
+    // ---------------- unified program (SPEC = false) / CONSUMER program (SPEC = true) ----------------
+    if constexpr (!SPEC) {
+        setup_rows();
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) rs1[i] = rs2[i] = 0.f;
+        // prologue: STAGES-1 slabs in flight
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < nkt) issue_tile(kt_begin + s, s);
+    }
     STAMP(1);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int it = 0; it < nkt; ++it) {
         // slab `it` has landed once at most the younger in-flight slabs remain outstanding
-        wait_younger<LOADS, STAGES - 2>(nkt - 1 - it);
+        if constexpr (!SPEC) wait_younger<LOADS, STAGES - 2>(nkt - 1 - it);
         __builtin_amdgcn_s_barrier(); // everyone's slab `it` is in LDS; everyone is done reading slab it-1
 
         // fragment reads for the whole slab first, then the DMA issue for slab it+STAGES-1 (its address arithmetic and
         // VMEM issue run under the LDS latency), then one uninterrupted MFMA cluster
         const f16* sA = smem + (it % STAGES) * STAGE;
         const f16* sB = sA + BM * 64;
+        // Big consumer tiles (>= 32 accumulator quads: 128 registers) cannot also hold the fragments of both K halves of the
+        // slab: they read and multiply one half at a time (below); everyone else reads the whole slab first.
+        constexpr bool HALF_AT_A_TIME = TM * TN >= 32;
         f16x8 xa[2][TM], wb[2][TN];
-        if (!(dbg & 4)) {
+        if (HALF_AT_A_TIME) {
+            // nothing to pre-read
+        } else if (!(dbg & 4) ) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -569,23 +692,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
                 for (int j = 0; j < TN; ++j) wb[ks][j] = zero8();
             }
         }
-        if (p.ln) {
-            // every lane re-reads the 16 bytes it DMA-ed into this slab (lane-linear image: conflict-free) -- all of
-            // the row's K columns pass through here, so the row statistics cost one extra LDS read per slab
+        if constexpr (!SPEC) {
+            if (p.ln) ln_accumulate(sA);
+        }
+        if constexpr (!SPEC) {
+            if (it + STAGES - 1 < nkt && !(dbg & 2)) issue_tile(kt_begin + it + STAGES - 1, (it + STAGES - 1) % STAGES);
+        }
+        if (HALF_AT_A_TIME) {
+            {
 #pragma unroll
-            for (int i = 0; i < A_LD; ++i) {
-                const f16x8 v = *reinterpret_cast<const f16x8*>(sA + (i * NW + wave) * 8 * 64 + lane * 8);
-                const f16x2 one2 = {(f16)1.0f, (f16)1.0f};
+                for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) { // v_dot2_f32_f16: two products + fp32 accumulate per instruction
-                    const f16x2 pr = {v[e], v[e + 1]};
-                    rs1[i] = __builtin_amdgcn_fdot2(pr, one2, rs1[i], false);
-                    rs2[i] = __builtin_amdgcn_fdot2(pr, pr, rs2[i], false);
+                    for (int i = 0; i < TM; ++i)
+                        xa[0][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WTM + i * 16 + frag_row, ks * 4 + frag_chunk));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        wb[0][j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(wb[0][j], xa[0][i], acc[i][j]);
                 }
             }
-        }
-        if (it + STAGES - 1 < nkt && !(dbg & 2)) issue_tile(kt_begin + it + STAGES - 1, (it + STAGES - 1) % STAGES);
-        if (!(dbg & 1)) {
+        } else if (!(dbg & 1) ) {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -609,27 +738,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
     __syncthreads(); // all fragment reads done before the epilogue tile overwrites the ring
     STAMP(2);
 
-    const int e_m = lane & 15;
-    const int e_n = (lane >> 4) * 4;
-    float* ln_stats = reinterpret_cast<float*>(smem_raw + (size_t)BM * SC * sizeof(f16)); // [BM][2] mean, rstd
     if (p.ln) {
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            float a1 = rs1[i], a2 = rs2[i];
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
-                a1 += __shfl_xor(a1, o);
-                a2 += __shfl_xor(a2, o);
-            }
-            if ((lane & 7) == 0) {
-                const float mean = a1 / (float)p.K;
-                float var = a2 / (float)p.K - mean * mean;
-                var = var < 0.f ? 0.f : var;
-                const int r = (i * NW + wave) * 8 + lrow;
-                ln_stats[2 * r] = mean;
-                ln_stats[2 * r + 1] = 1.0f / sqrtf(var + p.ln_eps);
-            }
-        }
+        if constexpr (!SPEC) ln_finalize();
         __syncthreads();
     }
     if (p.splits > 1) {
@@ -652,7 +762,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
         return;
     }
 
-    f16* sC = smem;
     if (p.geglu) {
         // 16-column blocks alternate [value | gate]; both live in the SAME lane (acc[i][j], acc[i][j+1]), so GEGLU is a
         // register-level product and the tile that goes to memory is half as wide
@@ -794,33 +903,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmP p, 
     __syncthreads();
     STAMP(3);
 
-    const int CPR = p.geglu ? BN / 16 : BN / 8; // 16-byte chunks per output tile row
-    const int n_out = p.geglu ? p.N / 2 : p.N;
-    const int n0_out = p.geglu ? n0 / 2 : n0;
-    const bool vec_ok = (n_out % 8 == 0) && (p.ldo % 8 == 0) && (p.residual == nullptr || p.ldr % 8 == 0);
-    for (int idx = tid; idx < BM * CPR; idx += NT) {
-        const int row = idx / CPR;
-        const int ch = idx - row * CPR;
-        const int m = m0 + row, n = n0_out + ch * 8;
-        if (m >= p.M || n >= n_out) continue;
-        f16x8 v = *reinterpret_cast<const f16x8*>(sC + row * SC + ch * 8);
-        if (vec_ok) {
-            if (p.residual != nullptr) {
-                const f16x8 rr = ldg8(p.residual + (size_t)m * p.ldr + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)rr[e]);
-            }
-            stg8(p.out + (size_t)m * p.ldo + n, v);
-        } else {
-            for (int e = 0; e < 8; ++e) {
-                if (n + e < n_out) {
-                    float f = (float)v[e];
-                    if (p.residual != nullptr) f += (float)p.residual[(size_t)m * p.ldr + n + e];
-                    p.out[(size_t)m * p.ldo + n + e] = (f16)f;
-                }
-            }
-        }
-    }
+    store_phase();
 #ifdef SDOD_GEMM_STAMP
     wait_vmcnt<0>();
     STAMP(4);
@@ -903,8 +986,10 @@ struct TileCfg {
 const TileCfg kTiles[] = {{0, 0},     {128, 128}, {128, 64}, {64, 64},   {256, 16}, {64, 128}, {128, 128},
                           {128, 64},  {64, 64},   {128, 128}, {256, 128}, {128, 64}, {256, 64},
                           {128, 128}, {128, 128}, {256, 128}, {256, 256}, {64, 64},  {128, 64}, {64, 128}, {128, 256},
-                          {64, 160},  {32, 160}};
-constexpr int kNumTiles = 22;
+                          {64, 160},  {32, 160},
+                          // 23..31: wave-specialised LDS-DMA kernel (4 consumer + 4 loader waves)
+                          {128, 128}, {128, 128}, {128, 256}, {256, 128}, {64, 64}, {64, 64}, {128, 64}, {64, 128}, {64, 160}};
+constexpr int kNumTiles = 31;
 
 const f16* zero_line() {
     static f16* z = nullptr;
@@ -915,21 +1000,21 @@ const f16* zero_line() {
     return z;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPEC = false>
 hipError_t launch_glds(const GemmP& p, dim3 grid, hipStream_t st) {
     constexpr size_t ring = (size_t)STAGES * (BM + BN) * 64 * sizeof(f16);
     constexpr size_t ctile = (size_t)BM * (BN + 8) * sizeof(f16) + (size_t)BM * 2 * sizeof(float); // + LayerNorm row stats
     constexpr size_t smem = (ring > ctile ? ring : ctile) + (size_t)3 * BN * sizeof(float); // + per-column epilogue vectors
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, STAGES>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, STAGES, SPEC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const f16* z = zero_line();
     if (!z) return hipErrorOutOfMemory;
-    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(64 * WM * WN), smem, st, p, z);
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, STAGES, SPEC>), grid, dim3(64 * WM * WN * (SPEC ? 2 : 1)), smem, st, p, z);
     return hipGetLastError();
 }
 
@@ -960,7 +1045,7 @@ Plan make_plan(const sdod_gemm_desc* d) {
     int tile = d->tile;
     const bool fused = d->geglu || d->k_tail || d->ln;
     if (fused && (tile < 6 || tile > kNumTiles)) tile = 14; // fusions live in the LDS-DMA kernel family only
-    if (d->geglu && (tile == 21 || tile == 22)) tile = 14;  // value/gate pairing needs an even number of 16-column blocks per wave
+    if (d->geglu && (tile == 21 || tile == 22 || tile == 31)) tile = 14;  // value/gate pairing needs an even number of 16-column blocks per wave
     if (tile <= 0 || tile > kNumTiles) {
         if (d->N <= 16) {
             tile = 4;
@@ -1037,6 +1122,14 @@ extern "C" __attribute__((visibility("default"))) int sdod_gemm_stamps(unsigned 
 
 extern "C" int sdod_gemm_num_tiles(void) { return kNumTiles; }
 
+extern "C" int sdod_gemm_tile_shape(int tile, int* bm, int* bn, int* lds_dma) {
+    if (tile < 1 || tile > kNumTiles) return sdod::INVALID_ARGUMENT;
+    if (bm) *bm = kTiles[tile].bm;
+    if (bn) *bn = kTiles[tile].bn;
+    if (lds_dma) *lds_dma = tile >= 6 ? 1 : 0;
+    return 0;
+}
+
 extern "C" int sdod_gemm_plan(const sdod_gemm_desc* d, int* tile, int* splits) {
     if (!d || d->K <= 0 || d->K % BK) return sdod::INVALID_ARGUMENT;
     const Plan pl = make_plan(d);
@@ -1112,8 +1205,8 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         p.sa0 = d->lda; p.sa1 = 0;
     }
     const Plan pl = make_plan(d);
-    SDOD_REQUIRE(!(d->geglu && (pl.tile == 21 || pl.tile == 22)), "geglu needs a tile with an even number of 16-column blocks per wave");
-    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln) || pl.tile >= 6, "geglu / tail segment / bias2 / ln need an LDS-DMA tile (6..22)");
+    SDOD_REQUIRE(!(d->geglu && (pl.tile == 21 || pl.tile == 22 || pl.tile == 31)), "geglu needs a tile with an even number of 16-column blocks per wave");
+    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln) || pl.tile >= 6, "geglu / tail segment / bias2 / ln need an LDS-DMA tile (6..31)");
     p.splits = pl.splits;
     p.kt_per_split = pl.kt_per_split;
     if (pl.splits > 1) {
@@ -1155,7 +1248,16 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     case 19: e = launch_glds<64, 128, 2, 2, 6>(p, grid, st); break;
     case 20: e = launch_glds<128, 256, 2, 4, 3>(p, grid, st); break;
     case 21: e = launch_glds<64, 160, 2, 2, 4>(p, grid, st); break;
-    default: e = launch_glds<32, 160, 2, 2, 6>(p, grid, st); break;
+    case 22: e = launch_glds<32, 160, 2, 2, 6>(p, grid, st); break;
+    case 23: e = launch_glds<128, 128, 2, 2, 4, true>(p, grid, st); break;
+    case 24: e = launch_glds<128, 128, 2, 2, 3, true>(p, grid, st); break;
+    case 25: e = launch_glds<128, 256, 2, 2, 3, true>(p, grid, st); break;
+    case 26: e = launch_glds<256, 128, 2, 2, 3, true>(p, grid, st); break;
+    case 27: e = launch_glds<64, 64, 2, 2, 8, true>(p, grid, st); break;
+    case 28: e = launch_glds<64, 64, 2, 2, 4, true>(p, grid, st); break;
+    case 29: e = launch_glds<128, 64, 2, 2, 6, true>(p, grid, st); break;
+    case 30: e = launch_glds<64, 128, 2, 2, 6, true>(p, grid, st); break;
+    default: e = launch_glds<64, 160, 2, 2, 4, true>(p, grid, st); break;
     }
     SDOD_HIP_CHECK(e);
     if (pl.splits > 1 && d->phase != 1) {

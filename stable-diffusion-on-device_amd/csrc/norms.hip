@@ -419,7 +419,11 @@ template <int V, int NT, int KMAX, bool RED>
 __global__ __launch_bounds__(NT) void gn_group_kernel(const GnG p) {
     typedef typename HalfVec<V>::T VT;
     __shared__ float red[NT / 64];
-    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    // workgroups b and b + 8 share an XCD (round-robin dispatch; speed only): give each XCD a run of CONSECUTIVE groups, whose
+    // 20..160-byte channel runs share cache lines, instead of every 8th group (each XCD's L2 would pull the whole tensor)
+    const int gpx = gridDim.x >> 3;
+    const int g = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * gpx + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int n = blockIdx.y, tid = threadIdx.x;
     const bool active = tid < p.ppp * p.vpp;
     const int pix0 = tid / p.vpp;
     const int c = g * p.Cg + (tid - pix0 * p.vpp) * V; // first of this thread's V channels (concatenated channel space)

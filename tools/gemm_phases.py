@@ -91,9 +91,9 @@ def main():
             lib.sdod_gemm_plan(ctypes.byref(desc), ctypes.byref(tt), ctypes.byref(sp))
             # grid size from the plan: the stamp table is indexed by workgroup
             from math import ceil
-            bm, bn = {6: (128, 128), 7: (128, 64), 8: (64, 64), 9: (128, 128), 10: (256, 128), 11: (128, 64), 12: (256, 64), 13: (128, 128),
-                      14: (128, 128), 15: (256, 128), 16: (256, 256), 17: (64, 64), 18: (128, 64), 19: (64, 128), 20: (128, 256),
-                      21: (64, 160), 22: (32, 160)}.get(tt.value, (0, 0))
+            bm_, bn_, dma_ = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            lib.sdod_gemm_tile_shape(tt.value, ctypes.byref(bm_), ctypes.byref(bn_), ctypes.byref(dma_))
+            bm, bn = (bm_.value, bn_.value) if dma_.value else (0, 0)
             if not bm:
                 print(f'{name:34s} {t:4d}  -- tile {tt.value} is not an LDS-DMA tile')
                 continue
