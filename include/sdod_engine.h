@@ -64,6 +64,12 @@ typedef struct sdod_model_config {
                           * blocks, last_hidden_state); 1 = OpenCLIP text tower as open_clip names it (`transformer.resblocks.N.*`,
                           * fused `attn.in_proj_*`, erf GELU) stopped after text_layers blocks + ln_final: SD2.x conditions on the
                           * PENULTIMATE block of ViT-H/14 (24 blocks in the checkpoint, text_layers = 23) */
+    int weight_quant;    /* 0: GEMM weights live in HBM as fp16 (an SDOD_U8Q checkpoint tensor is dequantised once at load);
+                          * 1 (UNET / TEMB graphs): every conv / linear weight must be given as SDOD_U8Q and STAYS affine uint8 in
+                          * HBM (half the weight footprint and stream, BASELINE config 5 "int8 weight quant (mirrors QNN quant
+                          * path)"): the GEMM expands the codes on the fragment read (sdod_gemm_desc.wq).  Costs two fusions the
+                          * fp16 build has: LayerNorm is a launch again (its gamma cannot be folded into integer codes) and the
+                          * ResBlock skip 1x1 conv is its own GEMM (its tensor has its own scale / offset). */
 } sdod_model_config;
 
 SDOD_API void sdod_model_config_sd14(sdod_model_config* cfg);

@@ -90,6 +90,15 @@ typedef struct sdod_gemm_desc {
     float ln_eps;
     int phase;                     /* split-K only: 0 = GEMM + reduce (default), 1 = GEMM slabs only, 2 = reduce + epilogue only
                                     * (lets a launch list time / profile the two kernels separately) */
+    /* --- int8 weight streaming (LDS-DMA kernel family only; BASELINE config 5, the reference's `quantize=8` path,
+     * todlc.py:105-108): w holds the affine-uint8 CODES of the reference's encoding real = (q + offset) * scale
+     * (qnn_context.cpp:1018-1033), one byte per element, row stride ldw BYTES; the slab is streamed as bytes (half the
+     * weight traffic of fp16) and expanded to fp16 (q - 128, exact) on the fragment read.  Per output column n:
+     * w_scale[n] = scale, w_off[n] = offset + 128 (fp32), so fused parameter groups may mix tensors with different
+     * encodings.  out = act(alpha * w_scale[n] * (sum_k A (q - 128) + w_off[n] * sum_k A) + bias ...).  Not with ln / k_tail. */
+    int wq;
+    const void* w_scale;           /* fp32 [N] */
+    const void* w_off;             /* fp32 [N] */
 } sdod_gemm_desc;
 
 SDOD_API int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream);

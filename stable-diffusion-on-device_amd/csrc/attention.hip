@@ -163,10 +163,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
     }
     __syncthreads();
 
+#ifdef SDOD_ATTN_ABLATE
+    constexpr int abl = SDOD_ATTN_ABLATE; // developer builds only (make lib/libsdod_attnabl<mask>.so): 1 = no K/V loads after tile 0,
+#else                                     // 2 = no exp in the softmax; results are wrong, only the timing is of interest
+    constexpr int abl = 0;
+#endif
     for (int t = 0; t < NT; ++t) {
         const int cur = t & 1;
         const bool has_next = t + 1 < NT;
-        if (has_next) load_tile(t + 1);
+        if (has_next && !(abl & 1)) load_tile(t + 1);
 
         const f16* sK = smem + cur * STAGE;
         const f16* sV = sK + KT * KSTR;
@@ -229,8 +234,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
                 for (int h2 = 0; h2 < 2; ++h2) {
                     f32x2 v = {s[a][c][2 * h2], s[a][c][2 * h2 + 1]};
                     v = v * sc2 + nm2; // packed fma
-                    v[0] = __builtin_amdgcn_exp2f(v[0]);
-                    v[1] = __builtin_amdgcn_exp2f(v[1]);
+                    if (!(abl & 2)) {
+                        v[0] = __builtin_amdgcn_exp2f(v[0]);
+                        v[1] = __builtin_amdgcn_exp2f(v[1]);
+                    }
                     if (!SUM_BY_MFMA) rs2 += v;
                     s[a][c][2 * h2] = v[0];
                     s[a][c][2 * h2 + 1] = v[1];

@@ -42,6 +42,8 @@ struct Param {
     size_t dev_bytes = 0;
     char* dev = nullptr;
     bool set = false;
+    bool quant = false; // kept as affine-uint8 codes in HBM (sdod_model_config.weight_quant); qrow = first row in qscale_/qoff_
+    size_t qrow = 0;
 };
 
 // activation tensor: NHWC fp16 (sequences: h = 1, w = tokens)
@@ -89,6 +91,12 @@ private:
     std::unordered_map<std::string, int> gindex_;
     char* weight_base_ = nullptr;
     size_t weight_bytes_ = 0;
+    float* qscale_ = nullptr; // per weight ROW (output channel): scale and offset + 128 of its tensor's encoding, laid out in the
+    float* qoff_ = nullptr;   // order of the weight arena, so that a fused parameter group is one contiguous run
+    size_t qrows_ = 0;
+    bool quant_mode() const { return cfg_.weight_quant != 0 && (kind_ == SDOD_GRAPH_UNET || kind_ == SDOD_GRAPH_TEMB); }
+    const float* qscale_of(int w) const { return params_[w].quant ? qscale_ + params_[w].qrow : nullptr; }
+    const float* qoff_of(int w) const { return params_[w].quant ? qoff_ + params_[w].qrow : nullptr; }
     int P(const std::string& name, std::vector<int64_t> shape, ParamKind kind, const std::string& group = "");
     // parameter stored as a column block [col_off, col_off + K) of a wider [rows][ld] fp16 matrix (owner < 0: allocates it)
     int Pc(const std::string& name, std::vector<int64_t> shape, ParamKind kind, int ld, int col_off, int owner);
@@ -158,6 +166,8 @@ private:
         const Act* tail1 = nullptr;
         int bias2 = -1;
         int ln_w = -1, ln_b = -1;  // fold LayerNorm(ln_w, ln_b) of the input rows into this Linear (see sdod_ln_fold_f16)
+        const float* wq_scale = nullptr; // uint8 weights (linear_raw on a fused group): per-row scale / offset + 128 vectors
+        const float* wq_off = nullptr;
     };
     struct FoldJob {
         f16* w; int n, k, ldw;
@@ -212,6 +222,7 @@ private:
     int kv_off_ = 0;
     std::vector<std::pair<std::string, int>> unet_res_blocks() const; // (prefix, cout) in declaration order
     const char* group_base(const std::string& group) const;
+    int group_first(const std::string& group) const; // index of the first parameter of a fused group
     void emit(std::function<void(hipStream_t)> fn, const char* label = "elementwise", double flops = 0, double bytes = 0) {
         settle();
         if (mode_ == REAL) sink().push_back(Op{std::move(fn), label, flops, bytes, ""});

@@ -58,6 +58,8 @@ Graph::~Graph() {
     for (auto& s : inputs_) (void)hipFree(s.ptr);
     for (auto& s : outputs_) (void)hipFree(s.ptr);
     (void)hipFree(weight_base_);
+    (void)hipFree(qscale_);
+    (void)hipFree(qoff_);
     (void)hipFree(arena_base_);
     (void)hipFree(ws_);
     (void)hipFree(gn_ws_);
@@ -68,6 +70,7 @@ Graph::~Graph() {
 // ------------------------------------------------------------------------------------------ parameters
 static size_t param_dev_bytes(const Param& p) {
     const auto& s = p.shape;
+    if (p.quant) return (size_t)s[0] * s[1] * (p.kind == PK_CONV3 ? 9 : 1); // one byte per code
     switch (p.kind) {
     case PK_CONV3: return (size_t)s[0] * s[1] * 9 * sizeof(f16);
     case PK_CONV3_SMALL: return (size_t)s[0] * 64 * sizeof(f16);
@@ -97,6 +100,7 @@ int Graph::P(const std::string& name, std::vector<int64_t> shape, ParamKind kind
     p.name = name;
     p.shape = std::move(shape);
     p.kind = kind;
+    p.quant = quant_mode() && (kind == PK_CONV3 || kind == PK_CONV1 || kind == PK_LINEAR || kind == PK_LINEAR_GEGLU);
     p.dev_bytes = param_dev_bytes(p);
     if (!group.empty()) {
         auto it = gindex_.find(group);
@@ -148,6 +152,22 @@ void Graph::allocate_weights() {
     SDOD_HIP_CHECK(hipMalloc((void**)&weight_base_, weight_bytes_));
     SDOD_HIP_CHECK(hipMemset(weight_base_, 0, weight_bytes_));
     for (size_t i = 0; i < params_.size(); ++i) params_[i].dev = weight_base_ + offs[i];
+    // rows of the uint8 weights, numbered in arena order (ascending device offset): members of a fused group are contiguous
+    {
+        std::vector<size_t> order;
+        for (size_t i = 0; i < params_.size(); ++i)
+            if (params_[i].quant) order.push_back(i);
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return offs[a] < offs[b]; });
+        qrows_ = 0;
+        for (size_t i : order) {
+            params_[i].qrow = qrows_;
+            qrows_ += (size_t)params_[i].shape[0];
+        }
+        if (qrows_) {
+            SDOD_HIP_CHECK(hipMalloc((void**)&qscale_, qrows_ * sizeof(float)));
+            SDOD_HIP_CHECK(hipMalloc((void**)&qoff_, qrows_ * sizeof(float)));
+        }
+    }
     for (auto& p : params_)
         if (p.owner >= 0) p.dev = params_[p.owner].dev + (size_t)p.col_off * sizeof(f16);
 }
@@ -228,6 +248,49 @@ void Graph::set_param(const std::string& name, const void* data, int dtype, cons
     // int8-weight checkpoints (BASELINE config 5, "mirrors the QNN quant path"): dequantised here, once, with the reference's
     // own arithmetic -- real = (q + offset) * scale evaluated in double, then rounded to float (qnn_context.cpp:1018-1033);
     // the kernels then run on the fp16 image of those values, exactly as they do for an fp16 checkpoint
+    if (p.quant) {
+        // the tensor stays affine uint8: repack the CODES exactly as the fp16 path repacks values (KRSC for 3x3 convs, 16-row
+        // value / gate interleave for GEGLU) and record its encoding for every output row
+        SDOD_REQUIRE(dtype == SDOD_U8Q, "graph was created with weight_quant = 1: '" + name + "' must be given as SDOD_U8Q");
+        bool same = (int)p.shape.size() == ndim;
+        for (int i = 0; same && i < ndim; ++i) same = p.shape[i] == shape[i];
+        if (!same && want == got && (p.kind == PK_CONV1 || p.kind == PK_LINEAR) && ndim >= 2 && shape[0] == p.shape[0]) same = true;
+        SDOD_REQUIRE(same, "shape mismatch for '" + name + "'");
+        float scale;
+        int32_t offset;
+        std::memcpy(&scale, data, 4);
+        std::memcpy(&offset, static_cast<const char*>(data) + 4, 4);
+        const uint8_t* q = static_cast<const uint8_t*>(data) + 8;
+        const int64_t rows = p.shape[0], kd = got / rows;
+        std::vector<uint8_t> staging((size_t)got);
+        uint8_t* dst = staging.data();
+        if (p.kind == PK_CONV3) {
+            const int64_t ci = p.shape[1];
+            parallel_for(rows, [&](int64_t b, int64_t e) {
+                for (int64_t o = b; o < e; ++o)
+                    for (int64_t c = 0; c < ci; ++c)
+                        for (int t = 0; t < 9; ++t) dst[o * kd + t * ci + c] = q[(o * ci + c) * 9 + t];
+            });
+        } else if (p.kind == PK_LINEAR_GEGLU) {
+            const int64_t H = rows / 2;
+            parallel_for(rows, [&](int64_t b, int64_t e) {
+                for (int64_t r = b; r < e; ++r) {
+                    const int64_t j = r < H ? r : r - H;
+                    const int64_t nr = (j / 16) * 32 + (r < H ? 0 : 16) + j % 16;
+                    std::memcpy(dst + nr * kd, q + r * kd, (size_t)kd);
+                }
+            });
+        } else {
+            std::memcpy(dst, q, (size_t)got);
+        }
+        SDOD_REQUIRE(p.ld == 0, "column-block parameters are not used with uint8 weights");
+        SDOD_HIP_CHECK(hipMemcpy(p.dev, staging.data(), (size_t)got, hipMemcpyHostToDevice));
+        std::vector<float> sv((size_t)rows, scale), ov((size_t)rows, (float)(offset + 128));
+        SDOD_HIP_CHECK(hipMemcpy(qscale_ + p.qrow, sv.data(), sv.size() * sizeof(float), hipMemcpyHostToDevice));
+        SDOD_HIP_CHECK(hipMemcpy(qoff_ + p.qrow, ov.data(), ov.size() * sizeof(float), hipMemcpyHostToDevice));
+        p.set = true;
+        return;
+    }
     std::vector<float> deq;
     if (dtype == SDOD_U8Q) {
         float scale;
@@ -416,7 +479,7 @@ IoSlot Graph::io(bool output, int index) const {
 // launch meets inside a replay: the UNet's weights are 1.7 GB, the Infinity Cache 256 MiB.  SDOD_AUTOTUNE=0 disables the
 // tuner (gemm.hip's static heuristic decides), SDOD_AUTOTUNE=hot ranks with back-to-back launches instead.
 namespace {
-const int kCandidates[] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 20, 21, 22, 23, 24, 27, 28, 29, 30, 31}; // (16, 25, 26: 128 accumulator registers spill)
+const int kCandidates[] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31}; // (25, 26 spill in their epilogue only; the tuner decides)
 
 struct ShapeKey {
     int v[12];
@@ -496,7 +559,7 @@ void*& tune_scratch() {
 }
 ShapeKey key_of(const sdod_gemm_desc& d) {
     return ShapeKey{{d.a_mode, d.M, d.N, d.K, d.c0, d.c1, d.stride, d.upsample, d.ksize, d.h_in,
-                     (d.residual ? 1 : 0) + (d.geglu ? 2 : 0) + 4 * d.tc0 + 16384 * d.tc1 + (d.ln ? (1 << 30) : 0), d.lda}};
+                     (d.residual ? 1 : 0) + (d.geglu ? 2 : 0) + 4 * d.tc0 + 16384 * d.tc1 + (d.ln ? (1 << 30) : 0) + (d.wq ? (1 << 29) : 0), d.lda}};
 }
 } // namespace
 
@@ -627,7 +690,13 @@ void Graph::linear_raw(const f16* x, int rows, int K, const f16* w, int ldw, int
         if (!o.ldo) d.ldo = N / 2;
         d.ldr = d.ldo;
     }
+    if (o.wq_scale) {
+        d.wq = 1;
+        d.w_scale = o.wq_scale;
+        d.w_off = o.wq_off;
+    }
     if (o.ln_w >= 0) {
+        if (d.wq) throw Error(INTERNAL_ERROR, "LayerNorm fold with uint8 weights");
         // LayerNorm folded into this Linear: gamma goes into W (in place, once, after all parameters are set), the
         // kernel gathers the row statistics itself; s/t are derived vectors owned by the graph
         d.ln = 1;
@@ -653,6 +722,13 @@ void Graph::linear_raw(const f16* x, int rows, int K, const f16* w, int ldw, int
 void Graph::linear(const f16* x, int rows, int K, int w, int N, f16* out, const GemmOpt& o) {
     const Param& p = params_[w];
     const int ldw = p.ld > 0 ? p.ld : p.kind == PK_CONV3_SMALL ? 64 : (int)(p.kind == PK_CONV3 ? p.shape[1] * 9 : p.shape[1]);
+    if (p.quant) { // (ldw counts elements, i.e. bytes for the uint8 codes)
+        GemmOpt oq = o;
+        oq.wq_scale = qscale_of(w);
+        oq.wq_off = qoff_of(w);
+        linear_raw(x, rows, K, reinterpret_cast<const f16*>(p.dev), ldw, N, out, oq);
+        return;
+    }
     linear_raw(x, rows, K, reinterpret_cast<const f16*>(p.dev), ldw, N, out, o);
 }
 
@@ -683,6 +759,12 @@ Act Graph::conv(const Act& x, const Act* x2, int w, int cout, int ksize, int str
     d.row_bias = o.row_bias; d.ld_row_bias = o.ld_row_bias; d.rows_per_img = o.rows_per_img;
     d.residual = o.residual; d.ldr = cout;
     d.act = o.act; d.alpha = o.alpha;
+    if (params_[w].quant) {
+        if (o.tail0) throw Error(INTERNAL_ERROR, "tail segment with uint8 weights");
+        d.wq = 1;
+        d.w_scale = qscale_of(w);
+        d.w_off = qoff_of(w);
+    }
     emit_gemm(d);
     return y;
 }

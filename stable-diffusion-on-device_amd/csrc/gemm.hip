@@ -59,6 +59,12 @@ struct GemmP {
     int bias_on_m;
     int splits, kt_per_split;
     int tiles_m, tiles_n;
+    // int8 weight streaming (config 5, "mirrors the QNN quant path"): W holds the affine-uint8 codes q of the reference's
+    // encoding real = (q + offset) * scale (qnn_context.cpp:1018-1033), one byte per element, [N][ldw bytes]; per output
+    // column n: w_scale[n] = scale, w_off[n] = offset + 128 (as float).  out = scale * (sum_k A (q - 128) + w_off * sum_k A).
+    int wq;
+    const float* w_scale;
+    const float* w_off;
 };
 
 constexpr int BK = 64;
@@ -355,13 +361,37 @@ __device__ unsigned long long g_stamp[8 * 8192];
 #define STAMP(i)
 #endif
 
+// 8 affine-uint8 weight codes (two dwords) -> f16x8 of (q - 128), exactly: byte b next to 0x64 is the fp16 number 1024 + b
+// (v_perm_b32 builds two of them per instruction), and one packed subtraction of 1152 centres it.  4 VALU per 8 weights.
+SDOD_DEVICE f16x8 u8x8_to_f16(u32x2 d) {
+    const uint32_t c64 = 0x64646464u;
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v w;
+    w[0] = __builtin_amdgcn_perm(c64, d[0], 0x04010400u);
+    w[1] = __builtin_amdgcn_perm(c64, d[0], 0x04030402u);
+    w[2] = __builtin_amdgcn_perm(c64, d[1], 0x04010400u);
+    w[3] = __builtin_amdgcn_perm(c64, d[1], 0x04030402u);
+    f16x8 h = __builtin_bit_cast(f16x8, w);
+    const f16x8 c = {(f16)1152.f, (f16)1152.f, (f16)1152.f, (f16)1152.f, (f16)1152.f, (f16)1152.f, (f16)1152.f, (f16)1152.f};
+    return h - c;
+}
+// fragment of weight row `row` (tile-local), K half `ks`, lane chunk `fc` (0..3), from the uint8 slab image (8-row groups at a
+// 1 KiB pitch, 64-byte rows, 16-byte chunks swizzled with (row >> 2) & 3)
+SDOD_DEVICE f16x8 wq_frag(const f16* sB, int row, int ks, int fc) {
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(sB) + (row >> 3) * 1024 + (row & 7) * 64;
+    const int chunk = (ks * 2 + (fc >> 1)) ^ ((row >> 2) & 3);
+    return u8x8_to_f16(*reinterpret_cast<const u32x2*>(base + chunk * 16 + (fc & 1) * 8));
+}
+
 // SPEC = wave specialisation: the workgroup is WM*WN CONSUMER waves (one per SIMD: fragment reads + MFMA, each owning a
 // (BM/WM)x(BN/WN) output tile) plus as many LOADER waves (their SIMD partners: nothing but the LDS-DMA issue of the slab
 // STAGES-1 ahead, and the LayerNorm-fold row statistics).  In the unspecialised form every wave does reads -> DMA issue ->
 // MFMA in series and the one barrier per slab keeps all waves in lockstep, so per slab the LDS read burst (~0.18 us at
 // 128x128), the DMA issue (~100-180 cycles per instruction, ~0.2 us) and the MFMA cluster (~0.24 us) ADD UP (0.70 us
 // measured, tools/gemm_phases.py); with the roles split they overlap between the same barriers.
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPEC = false>
+// WQ = the weight operand is affine uint8 (GemmP::wq): a compile-time variant, so that the fp16 kernels carry none of its code
+// or registers (several sit exactly at the 128-register step that lets two workgroups share a CU).
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPEC = false, bool WQ = false>
 __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kernel(const GemmP p, const f16* __restrict__ zeros) {
     constexpr int NC = WM * WN;                   // waves that own output tiles
     constexpr int NW = SPEC ? 2 * NC : NC;        // waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD)
@@ -450,8 +480,18 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
         }
     #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
-            const int n = n0 + (i * NL + lw) * 8 + lrow;
-            b_row[i] = n < p.N ? p.w + (size_t)n * p.ldw + lchunk * 8 : zeros;
+            if (!WQ) {
+                const int n = n0 + (i * NL + lw) * 8 + lrow;
+                b_row[i] = n < p.N ? p.w + (size_t)n * p.ldw + lchunk * 8 : zeros;
+            } else {
+                // uint8 weights: a slab row is 64 bytes = 4 chunks of 16; lanes 0..31 of a DMA instruction cover the same 8 rows
+                // (lanes 32..63 idle, so the instruction count -- and the vmcnt arithmetic -- equals the fp16 form); chunks
+                // are XOR-swizzled with (row >> 2) & 3 so that the 8-byte fragment reads of 16 rows hit 16 different bank pairs
+                const int r = (i * NL + lw) * 8 + ((lane & 31) >> 2);
+                const int n = n0 + r;
+                const int lc = (lane & 3) ^ ((r >> 2) & 3);
+                b_row[i] = n < p.N ? reinterpret_cast<const f16*>(reinterpret_cast<const unsigned char*>(p.w) + (size_t)n * p.ldw + lc * 16) : zeros;
+            }
         }
     };
     const int cin = p.c0 + p.c1;
@@ -477,8 +517,8 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
             }
 #pragma unroll
             for (int i = 0; i < B_LD; ++i) {
-                const f16* g = b_row[i] + (b_row[i] == zeros ? 0 : k0);
-                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * NL + lw) * 8 * 64), 16, 0, 0);
+                const f16* g = b_row[i] + (b_row[i] == zeros ? 0 : (WQ ? k0 >> 1 : k0));
+                if (!WQ || lane < 32) __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * NL + lw) * 8 * 64), 16, 0, 0);
             }
             return;
         }
@@ -510,8 +550,8 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
-            const f16* g = b_row[i] + (b_row[i] == zeros ? 0 : k0);
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * NL + lw) * 8 * 64), 16, 0, 0);
+            const f16* g = b_row[i] + (b_row[i] == zeros ? 0 : (WQ ? k0 >> 1 : k0));
+            if (!WQ || lane < 32) __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * NL + lw) * 8 * 64), 16, 0, 0);
         }
     };
 
@@ -549,7 +589,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                 float var = a2 / (float)p.K - mean * mean;
                 var = var < 0.f ? 0.f : var;
                 const int r = (i * NL + lw) * 8 + lrow;
-                ln_stats[2 * r] = mean;
+                ln_stats[2 * r] = WQ ? a1 : mean; // uint8 weights: the plain row sum of A over this workgroup's K range
                 ln_stats[2 * r + 1] = 1.0f / sqrtf(var + p.ln_eps);
             }
         }
@@ -560,14 +600,15 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
     // the main loop returns; the epilogue then has no dependent global loads.  Absent vectors / columns past N read the zero line.
     constexpr size_t RING_BYTES = (size_t)STAGES * STAGE * sizeof(f16);
     constexpr size_t CTILE_BYTES = (size_t)BM * SC * sizeof(f16) + (size_t)BM * 2 * sizeof(float);
-    float* colv = reinterpret_cast<float*>(smem_raw + (RING_BYTES > CTILE_BYTES ? RING_BYTES : CTILE_BYTES)); // [3][BN]
+    float* colv = reinterpret_cast<float*>(smem_raw + (RING_BYTES > CTILE_BYTES ? RING_BYTES : CTILE_BYTES)); // [4][BN]
     {
         constexpr int CHUNKS = (BN + 63) / 64;
         const float* zf = reinterpret_cast<const float*>(zeros) + lane;
-        for (int job = wave; job < 3 * CHUNKS; job += NW) { // wave-uniform
+        for (int job = wave; job < 4 * CHUNKS; job += NW) { // wave-uniform
             const int vec = job / CHUNKS, q = job - vec * CHUNKS;
             const int c = q * 64 + lane, n = n0 + c;
-            const float* base = vec == 0 ? ((p.bias != nullptr && !p.bias_on_m) ? p.bias : nullptr) : vec == 1 ? p.bias2 : (p.ln ? p.ln_s : nullptr);
+            const float* base = vec == 0 ? ((p.bias != nullptr && !p.bias_on_m) ? p.bias : nullptr) : vec == 1 ? p.bias2
+                              : vec == 2 ? (p.ln ? p.ln_s : WQ ? p.w_off : nullptr) : (WQ ? p.w_scale : nullptr);
             const float* g = (base != nullptr && n < p.N) ? base + n : zf;
             if (c < BN) __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(colv + vec * BN + q * 64), 4, 0, 0);
         }
@@ -618,13 +659,13 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
             for (int it = 0; it < nkt; ++it) {
                 wait_younger<LOADS, STAGES - 2>(nkt - 1 - it); // slab `it` of THIS wave has landed ...
                 __builtin_amdgcn_s_barrier();                  // ... and everybody's; slab it-1 is no longer read
-                if (p.ln) ln_accumulate(smem + (it % STAGES) * STAGE);
+                if (p.ln || WQ) ln_accumulate(smem + (it % STAGES) * STAGE);
                 if (it + STAGES - 1 < nkt) issue_tile(kt_begin + it + STAGES - 1, (it + STAGES - 1) % STAGES);
             }
             wait_vmcnt<0>();
             __syncthreads();
             STAMP(2);
-            if (p.ln) {
+            if (p.ln || WQ) {
                 ln_finalize();
                 __syncthreads();
             }
@@ -681,7 +722,8 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                 xa[ks][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WTM + i * 16 + frag_row, ks * 4 + frag_chunk));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                wb[ks][j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
+                wb[ks][j] = WQ ? wq_frag(sB, wn * WTN + j * 16 + frag_row, ks, frag_chunk)
+                                 : *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
         }
         } else {
 #pragma unroll
@@ -693,7 +735,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
             }
         }
         if constexpr (!SPEC) {
-            if (p.ln) ln_accumulate(sA);
+            if (p.ln || WQ) ln_accumulate(sA);
         }
         if constexpr (!SPEC) {
             if (it + STAGES - 1 < nkt && !(dbg & 2)) issue_tile(kt_begin + it + STAGES - 1, (it + STAGES - 1) % STAGES);
@@ -707,11 +749,13 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                         xa[0][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WTM + i * 16 + frag_row, ks * 4 + frag_chunk));
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        wb[0][j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
+                        wb[0][j] = WQ ? wq_frag(sB, wn * WTN + j * 16 + frag_row, ks, frag_chunk)
+                                        : *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
 #pragma unroll
                         for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(wb[0][j], xa[0][i], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0); // keep the second half's fragment reads behind these MFMAs (registers)
                 }
             }
         } else if (!(dbg & 1) ) {
@@ -738,9 +782,23 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
     __syncthreads(); // all fragment reads done before the epilogue tile overwrites the ring
     STAMP(2);
 
-    if (p.ln) {
+    if (p.ln || WQ) {
         if constexpr (!SPEC) ln_finalize();
         __syncthreads();
+    }
+    if (WQ) {
+        // affine-uint8 weights: acc holds sum_k A (q - 128); out = scale_n * (acc + (offset_n + 128) * sum_k A)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float rsum = ln_stats[2 * (wm * WTM + i * 16 + e_m)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = wn * WTN + j * 16 + e_n;
+                const f32x4 of = *reinterpret_cast<const f32x4*>(colv + 2 * BN + nl), sc = *reinterpret_cast<const f32x4*>(colv + 3 * BN + nl);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] + rsum * of[r]) * sc[r];
+            }
+        }
     }
     if (p.splits > 1) {
         float* slab = p.partial + (size_t)split * p.M * p.N;
@@ -1000,21 +1058,21 @@ const f16* zero_line() {
     return z;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPEC = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPEC = false, bool WQ = false>
 hipError_t launch_glds(const GemmP& p, dim3 grid, hipStream_t st) {
     constexpr size_t ring = (size_t)STAGES * (BM + BN) * 64 * sizeof(f16);
     constexpr size_t ctile = (size_t)BM * (BN + 8) * sizeof(f16) + (size_t)BM * 2 * sizeof(float); // + LayerNorm row stats
-    constexpr size_t smem = (ring > ctile ? ring : ctile) + (size_t)3 * BN * sizeof(float); // + per-column epilogue vectors
+    constexpr size_t smem = (ring > ctile ? ring : ctile) + (size_t)4 * BN * sizeof(float); // + per-column epilogue vectors
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, STAGES, SPEC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, STAGES, SPEC, WQ>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const f16* z = zero_line();
     if (!z) return hipErrorOutOfMemory;
-    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, STAGES, SPEC>), grid, dim3(64 * WM * WN * (SPEC ? 2 : 1)), smem, st, p, z);
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, STAGES, SPEC, WQ>), grid, dim3(64 * WM * WN * (SPEC ? 2 : 1)), smem, st, p, z);
     return hipGetLastError();
 }
 
@@ -1043,9 +1101,10 @@ Plan make_plan(const sdod_gemm_desc* d) {
     const int KT = d->K / BK;
     auto ntiles = [&](int t) { return ((d->M + kTiles[t].bm - 1) / kTiles[t].bm) * ((d->N + kTiles[t].bn - 1) / kTiles[t].bn); };
     int tile = d->tile;
-    const bool fused = d->geglu || d->k_tail || d->ln;
+    const bool fused = d->geglu || d->k_tail || d->ln || d->wq;
     if (fused && (tile < 6 || tile > kNumTiles)) tile = 14; // fusions live in the LDS-DMA kernel family only
-    if (d->geglu && (tile == 21 || tile == 22 || tile == 31)) tile = 14;  // value/gate pairing needs an even number of 16-column blocks per wave
+    if (d->geglu && (tile == 21 || tile == 22 || tile == 31)) tile = 14;
+    if (d->wq && !(tile == 8 || tile == 13 || tile == 23 || tile == 24 || (tile >= 27 && tile <= 30))) tile = 23; // uint8-weight variants  // value/gate pairing needs an even number of 16-column blocks per wave
     if (tile <= 0 || tile > kNumTiles) {
         if (d->N <= 16) {
             tile = 4;
@@ -1144,7 +1203,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     SDOD_REQUIRE(d->a && d->w && d->out, "null operand pointer");
     SDOD_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "M, N, K must be positive");
     SDOD_REQUIRE(d->K % BK == 0, "K must be a multiple of 64 (pad the weight / use im2col for Cin<64)");
-    SDOD_REQUIRE(d->ldw >= d->K && d->ldw % 8 == 0, "ldw must be >= K and a multiple of 8");
+    SDOD_REQUIRE(d->ldw >= d->K && d->ldw % (d->wq ? 16 : 8) == 0, "ldw must be >= K and keep rows 16-byte aligned");
     SDOD_REQUIRE(d->ldo >= (d->geglu ? d->N / 2 : d->N), "ldo must be >= N");
     SDOD_REQUIRE(((uintptr_t)d->a & 15) == 0 && ((uintptr_t)d->w & 15) == 0, "operands must be 16-byte aligned");
     GemmP p{};
@@ -1171,6 +1230,10 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     p.ln_s = (const float*)d->ln_s;
     p.ln_eps = d->ln_eps;
     if (d->ln) SDOD_REQUIRE(d->a_mode == SDOD_A_ROWS && d->ln_s != nullptr && !d->bias_on_m, "ln fold needs rows mode and ln_s");
+    p.wq = d->wq ? 1 : 0;
+    p.w_scale = (const float*)d->w_scale;
+    p.w_off = (const float*)d->w_off;
+    if (d->wq) SDOD_REQUIRE(d->w_scale && d->w_off && !d->ln && !d->k_tail && !d->bias_on_m, "uint8 weights need w_scale / w_off and exclude ln, k_tail, bias_on_m");
     if (d->geglu) {
         SDOD_REQUIRE(d->N % 32 == 0 && !d->residual && !d->row_bias && !d->bias_on_m && d->act == 0, "geglu: N % 32 == 0, no residual/row_bias/act");
         SDOD_REQUIRE(d->ldo >= d->N / 2, "geglu: ldo must be >= N/2");
@@ -1206,7 +1269,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     }
     const Plan pl = make_plan(d);
     SDOD_REQUIRE(!(d->geglu && (pl.tile == 21 || pl.tile == 22 || pl.tile == 31)), "geglu needs a tile with an even number of 16-column blocks per wave");
-    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln) || pl.tile >= 6, "geglu / tail segment / bias2 / ln need an LDS-DMA tile (6..31)");
+    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln || d->wq) || pl.tile >= 6, "geglu / tail segment / bias2 / ln / uint8 weights need an LDS-DMA tile (6..31)");
     p.splits = pl.splits;
     p.kt_per_split = pl.kt_per_split;
     if (pl.splits > 1) {
@@ -1225,7 +1288,18 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     SDOD_REQUIRE(d->phase >= 0 && d->phase <= 2 && (d->phase == 0 || pl.splits > 1), "phase 1/2 only apply to a split-K plan");
     hipError_t e = hipSuccess;
-    if (d->phase != 2)
+    if (d->phase != 2 && d->wq)
+    switch (pl.tile) { // the uint8-weight variants (make_plan maps every other tile onto one of these)
+    case 8: e = launch_glds<64, 64, 2, 2, 4, false, true>(p, grid, st); break;
+    case 13: e = launch_glds<128, 128, 2, 4, 4, false, true>(p, grid, st); break;
+    case 24: e = launch_glds<128, 128, 2, 2, 3, true, true>(p, grid, st); break;
+    case 27: e = launch_glds<64, 64, 2, 2, 8, true, true>(p, grid, st); break;
+    case 28: e = launch_glds<64, 64, 2, 2, 4, true, true>(p, grid, st); break;
+    case 29: e = launch_glds<128, 64, 2, 2, 6, true, true>(p, grid, st); break;
+    case 30: e = launch_glds<64, 128, 2, 2, 6, true, true>(p, grid, st); break;
+    default: e = launch_glds<128, 128, 2, 2, 4, true, true>(p, grid, st); break; // 23
+    }
+    else if (d->phase != 2)
     switch (pl.tile) {
     case 1: e = launch_cfg<128, 128, 2, 2>(p, grid, st); break;
     case 2: e = launch_cfg<128, 64, 2, 2>(p, grid, st); break;

@@ -21,6 +21,12 @@ static void check_rc2(int rc) {
     if (rc != 0) throw Error(rc, get_last_error());
 }
 
+int Graph::group_first(const std::string& group) const {
+    auto it = gindex_.find(group);
+    if (it == gindex_.end()) throw Error(INTERNAL_ERROR, "unknown parameter group " + group);
+    return groups_[it->second].front();
+}
+
 const char* Graph::group_base(const std::string& group) const {
     auto it = gindex_.find(group);
     if (it == gindex_.end()) throw Error(INTERNAL_ERROR, "unknown parameter group " + group);
@@ -36,7 +42,12 @@ Act Graph::res_block(const std::string& pfx, const Act& x, const Act* x2, int co
     // out_layers.3 (3x3) and skip_connection (1x1) share ONE weight matrix [cout][9*cout + cin]: the skip conv is the tail
     // K-segment of the same GEMM (one launch, no intermediate skip tensor)
     int c2w, skw = -1, skb = -1;
-    if (cin != cout) {
+    const bool fuse_skip = !quant_mode(); // uint8 weights: the skip conv's tensor has its own encoding -> its own GEMM
+    if (cin != cout && !fuse_skip) {
+        c2w = P(pfx + ".out_layers.3.weight", {cout, cout, 3, 3}, PK_CONV3);
+        skw = P(pfx + ".skip_connection.weight", {cout, cin, 1, 1}, PK_CONV1);
+        skb = P(pfx + ".skip_connection.bias", {cout}, PK_VEC);
+    } else if (cin != cout) {
         const int ld = 9 * cout + cin;
         c2w = Pc(pfx + ".out_layers.3.weight", {cout, cout, 3, 3}, PK_CONV3, ld, 0, -1);
         skw = Pc(pfx + ".skip_connection.weight", {cout, cin, 1, 1}, PK_CONV1, ld, 9 * cout, c2w);
@@ -61,7 +72,13 @@ Act Graph::res_block(const std::string& pfx, const Act& x, const Act* x2, int co
     release(h);
     GemmOpt o2;
     o2.bias = c2b;
-    if (cin != cout) {
+    Act sk;
+    if (cin != cout && !fuse_skip) {
+        GemmOpt os;
+        os.bias = skb;
+        sk = conv(x, x2, skw, cout, 1, 1, false, os); // 1x1 over the (possibly concatenated) block input
+        o2.residual = sk.p;
+    } else if (cin != cout) {
         o2.tail0 = &x;
         o2.tail1 = x2;
         o2.bias2 = skb;
@@ -71,6 +88,7 @@ Act Graph::res_block(const std::string& pfx, const Act& x, const Act* x2, int co
     }
     Act out = conv(g2, nullptr, c2w, cout, 3, 1, false, o2);
     release(g2);
+    if (sk.p) release_after_consumer(sk);
     return out;
 }
 
@@ -111,10 +129,20 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     { GemmOpt o; o.bias = pib; linear(g.p, rows, C, piw, C, t0.p, o); }
     release(g);
     // self-attention
-    // the three LayerNorms of the block are folded into the Linear that consumes them (no LN launch, no LN tensor)
+    // the three LayerNorms of the block are folded into the Linear that consumes them (no LN launch, no LN tensor) -- except
+    // with uint8 weights, whose integer codes cannot absorb gamma: there LayerNorm is a launch and the Linear a plain one
+    const bool fold = !quant_mode();
+    auto normed = [&](const Act& src, int lw, int lb) -> Act { return layer_norm(src, lw, lb, 1e-5f); };
     f16* qkv = alloc((size_t)rows * 3 * C);
-    { GemmOpt o; o.ln_w = l1w; o.ln_b = l1b;
-      linear_raw(t0.p, rows, C, reinterpret_cast<const f16*>(group_base(gq)), C, 3 * C, qkv, o); }
+    if (fold) {
+        GemmOpt o; o.ln_w = l1w; o.ln_b = l1b;
+        linear_raw(t0.p, rows, C, reinterpret_cast<const f16*>(group_base(gq)), C, 3 * C, qkv, o);
+    } else {
+        Act nrm = normed(t0, l1w, l1b);
+        GemmOpt o; o.wq_scale = qscale_of(group_first(gq)); o.wq_off = qoff_of(group_first(gq));
+        linear_raw(nrm.p, rows, C, reinterpret_cast<const f16*>(group_base(gq)), C, 3 * C, qkv, o);
+        release(nrm);
+    }
     f16* a1 = alloc((size_t)rows * C);
     attention(qkv, qkv + C, qkv + 2 * C, a1, B, heads, L, L, d, 3 * C, 3 * C, 3 * C, C, false);
     release(qkv);
@@ -123,7 +151,13 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     release(a1); release(t0);
     // cross-attention on the text context
     f16* q2 = alloc((size_t)rows * C);
-    { GemmOpt o; o.ln_w = l2w; o.ln_b = l2b; linear(t1.p, rows, C, q2w, C, q2, o); }
+    if (fold) {
+        GemmOpt o; o.ln_w = l2w; o.ln_b = l2b; linear(t1.p, rows, C, q2w, C, q2, o);
+    } else {
+        Act nrm = normed(t1, l2w, l2b);
+        linear(nrm.p, rows, C, q2w, C, q2, GemmOpt{});
+        release(nrm);
+    }
     const int Lk = ctx.w;
     const f16* kv = kv_all_ + my_kv;
     f16* a2 = alloc((size_t)rows * C);
@@ -134,7 +168,13 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     release(a2); release(t1);
     // GEGLU feed-forward
     f16* gg = alloc((size_t)rows * 4 * C); // GEGLU fused into the ff.net.0.proj epilogue: the [rows][8C] tensor never exists
-    { GemmOpt o; o.bias = f1b; o.geglu = true; o.ln_w = l3w; o.ln_b = l3b; linear(t2.p, rows, C, f1w, 8 * C, gg, o); }
+    if (fold) {
+        GemmOpt o; o.bias = f1b; o.geglu = true; o.ln_w = l3w; o.ln_b = l3b; linear(t2.p, rows, C, f1w, 8 * C, gg, o);
+    } else {
+        Act nrm = normed(t2, l3w, l3b);
+        GemmOpt o; o.bias = f1b; o.geglu = true; linear(nrm.p, rows, C, f1w, 8 * C, gg, o);
+        release(nrm);
+    }
     Act t3 = act(B, 1, L, C);
     { GemmOpt o; o.bias = f2b; o.residual = t2.p; linear(gg, rows, 4 * C, f2w, C, t3.p, o); }
     release(gg); release(t2);
@@ -170,8 +210,10 @@ void Graph::build_unet() {
     // cross-attention K/V of ALL transformers: one GEMM on the text context, re-run only when the context changes
     if (mode_ != DECLARE && kv_total_ > 0) {
         to_static_ = true;
+        GemmOpt okv;
+        if (quant_mode()) { okv.wq_scale = qscale_of(group_first("attn2_kv_all")); okv.wq_off = qoff_of(group_first("attn2_kv_all")); }
         linear_raw(ctx_in, B * CL, cd, reinterpret_cast<const f16*>(group_base("attn2_kv_all")), cd, kv_total_,
-                   mode_ == REAL ? kv_all_ : ctx_in /* placeholder during the sizing pass */, GemmOpt{});
+                   mode_ == REAL ? kv_all_ : ctx_in /* placeholder during the sizing pass */, okv);
         to_static_ = false;
     }
 
@@ -299,6 +341,7 @@ void Graph::build_temb() {
     if (mode_ != DECLARE) {
         GemmOpt o;
         o.bias_raw = reinterpret_cast<const float*>(group_base("emb_b"));
+        if (quant_mode()) { o.wq_scale = qscale_of(group_first("emb_w")); o.wq_off = qoff_of(group_first("emb_w")); }
         linear_raw(emb, B, EC, reinterpret_cast<const f16*>(group_base("emb_w")), EC, total, out, o);
     }
     release(feat); release(hmid); release(emb);

@@ -54,6 +54,7 @@ class GemmDesc(ctypes.Structure):
         ('act', c_int), ('alpha', c_float), ('bias_on_m', c_int), ('split_k', c_int), ('tile', c_int),
         ('geglu', c_int), ('k_tail', c_int), ('t0', c_void_p), ('t1', c_void_p), ('tc0', c_int), ('tc1', c_int),
         ('bias2', c_void_p), ('ln', c_int), ('ln_s', c_void_p), ('ln_eps', c_float), ('phase', c_int),
+        ('wq', c_int), ('w_scale', c_void_p), ('w_off', c_void_p),
     ]
 
 

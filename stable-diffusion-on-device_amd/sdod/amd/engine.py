@@ -16,7 +16,7 @@ class ModelConfig(ctypes.Structure):
     """mirror of `struct sdod_model_config`"""
     _fields_ = [(n, ctypes.c_int) for n in (
         'latent_channels', 'latent_h', 'latent_w', 'model_channels', 'context_dim', 'context_len', 'num_heads',
-        'head_dim', 'vocab_size', 'text_layers', 'text_heads', 'vae_channels', 'linear_proj', 'text_arch')]
+        'head_dim', 'vocab_size', 'text_layers', 'text_heads', 'vae_channels', 'linear_proj', 'text_arch', 'weight_quant')]
 
 
 ENGINE_SYMBOLS = [

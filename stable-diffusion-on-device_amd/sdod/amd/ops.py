@@ -46,14 +46,19 @@ def workspace(nbytes, device, tag='default'):
 
 def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=None, alpha=1.0, out=None,
          conv=None, a2=None, bias_on_m=False, split_k=0, tile=0, time_iters=0, geglu=False, tail=None, bias2=None,
-         ln_s=None, ln_eps=1e-5, cold_scratch=None, phase=0, return_desc=False):
+         ln_s=None, ln_eps=1e-5, cold_scratch=None, phase=0, return_desc=False, w_scale=None, w_off=None):
     """out = act(alpha * A @ W^T + bias + row_bias) + residual.
 
     a: fp16 [M, K] (rows mode) or NHWC [N, H, W, C0] with conv=dict(stride=1|2, upsample=bool) (3x3 pad 1);
     a2: optional second NHWC source concatenated on channels; w: fp16 [Nout, K] (conv: K = 9*(C0+C1), KRSC)."""
     lib = _lib.hip()
-    _req(a, torch.float16, 'a'); _req(w, torch.float16, 'w')
+    _req(a, torch.float16, 'a')
     d = GemmDesc()
+    if w_scale is not None:   # affine-uint8 weight codes: real = (q + offset) * scale, w_off = offset + 128 per output column
+        _req(w, torch.uint8, 'w'); _req(w_scale, torch.float32, 'w_scale'); _req(w_off, torch.float32, 'w_off')
+        d.wq = 1; d.w_scale = _p(w_scale); d.w_off = _p(w_off)
+    else:
+        _req(w, torch.float16, 'w')
     nout, k = w.shape
     if conv is None:
         m = a.shape[0]

@@ -16,7 +16,7 @@ from .samplers import PLMS_ORDERS, PlmsSchedule
 
 class Txt2Img:
     def __init__(self, state_dicts=None, models_dir=None, images_per_gpu=1, latent_hw=64, device='cuda:0', use_hip_graph=True,
-                 tokenizer=None, with_text_encoder=True, model='sd14', with_vae=True, cfg_split=False):
+                 tokenizer=None, with_text_encoder=True, model='sd14', with_vae=True, cfg_split=False, weight_quant=None):
         """state_dicts: {'unet': sd, 'temb': sd, 'text': sd, 'vae': sd} in ldm/HF naming (canonical layouts; values may be
         weights.QuantU8 for an int8-weight checkpoint), or models_dir with the .sdodw containers libsdod_setup uses.
         model='sd21': SD v2.1-768 (BASELINE config 5): UNet with 64-wide heads / context 1024, v-prediction, OpenCLIP
@@ -27,6 +27,12 @@ class Txt2Img:
         self.model = model
         self.v_prediction = model == 'sd21'
         self.cfg = E.sd21_config(latent_hw, latent_hw) if model == 'sd21' else E.sd14_config(latent_hw, latent_hw)
+        # int8 weight streaming (BASELINE config 5): when the UNet checkpoint holds affine-uint8 tensors (weights.QuantU8, the
+        # reference's QNN encoding) they stay uint8 in HBM and the GEMMs expand them on the fly; weight_quant=False keeps the
+        # round-1 behaviour (dequantise once at load, fp16 in HBM)
+        if weight_quant is None:
+            weight_quant = state_dicts is not None and any(hasattr(v, 'payload') and len(v.shape) >= 2 for v in state_dicts['unet'].values())
+        self.cfg.weight_quant = 1 if weight_quant else 0
         # latency mode: the two halves of the classifier-free-guidance batch run on TWO GPUs -- even rank =
         # unconditional, odd rank = conditional -- and exchange their [n,H,W,4] fp16 predictions once per UNet evaluation
         # (32 KB per image over xGMI); everything after the exchange is computed redundantly, so both ranks hold the image

@@ -69,6 +69,56 @@ def test_gemm_rows(m, n, k, tile):
     check(out, ref, name=f'gemm {m}x{n}x{k} tile{tile}')
 
 
+@pytest.mark.parametrize('tile', [0, 8, 13, 20, 21, 23, 27, 28, 29, 30, 31])
+@pytest.mark.parametrize('case', ['rows', 'rows_split', 'conv', 'geglu'])
+def test_gemm_uint8_weight_streaming(case, tile):
+    """int8 weight path of BASELINE config 5: W stays affine-uint8 in memory (the reference's QNN encoding real = (q + offset) * scale,
+    qnn_context.cpp:1018-1033), per-column (scale, offset) so that fused parameter groups can mix tensors; the reference for
+    the check is the fp32 product with the DEQUANTISED weights."""
+    from sdod.amd import ops
+    g = torch.Generator().manual_seed(130)
+    d = dev()
+
+    def quant(n, k):
+        q = torch.randint(0, 256, (n, k), generator=g, dtype=torch.uint8)
+        scale = (torch.rand(n, generator=g) * 0.5 + 0.75) * 2.0 / 255 * k ** -0.5        # two "tensors" with different encodings
+        offset = torch.where(torch.arange(n) < n // 2, torch.tensor(-128.0), torch.tensor(-101.0))
+        scale = torch.where(torch.arange(n) < n // 2, scale, scale * 1.7)
+        wf = (q.float() + offset[:, None]) * scale[:, None]
+        return q, scale.float(), (offset + 128).float(), wf
+
+    if case in ('rows', 'rows_split'):
+        m, n, k = (600, 320, 1280) if case == 'rows' else (128, 1280, 2560)
+        a = rnd((m, k), 131)
+        q, sc, of, wf = quant(n, k)
+        bias = torch.randn(n, generator=g); res = rnd((m, n), 132)
+        ref = (a.float() @ wf.t() + bias).half().float() + res.float()
+        out = ops.gemm(a.to(d), q.to(d), bias.to(d), residual=res.to(d), w_scale=sc.to(d), w_off=of.to(d), tile=tile,
+                       split_k=4 if case == 'rows_split' else 1)
+    elif case == 'conv':
+        nb, h, w_, cin, cout = 2, 16, 16, 128, 192
+        x = rnd((nb, h, w_, cin), 133)
+        q, sc, of, wf = quant(cout, 9 * cin)
+        bias = torch.randn(cout, generator=g)
+        ref = conv_ref(x, wf.half(), bias) if False else F.conv2d(x.float().permute(0, 3, 1, 2), wf.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1)
+        out = ops.gemm(x.to(d), q.to(d), bias.to(d), conv=dict(stride=1), w_scale=sc.to(d), w_off=of.to(d), tile=tile)
+    else:
+        m, c = 300, 320
+        x = rnd((m, c), 134)
+        q, sc, of, wf = quant(8 * c, c)
+        b = torch.randn(8 * c, generator=g)
+        y = x.float() @ wf.t() + b
+        H = 4 * c
+        ref = y[:, :H] * F.gelu(y[:, H:])
+        perm = torch.empty(2 * H, dtype=torch.long)
+        j = torch.arange(H)
+        perm[(j // 16) * 32 + j % 16] = j
+        perm[(j // 16) * 32 + 16 + j % 16] = H + j
+        out = ops.gemm(x.to(d), q[perm].contiguous().to(d), b[perm].contiguous().to(d), geglu=True, w_scale=sc[perm].contiguous().to(d),
+                       w_off=of[perm].contiguous().to(d), tile=tile)
+    check(out, ref, name=f'uint8 weights {case} tile{tile}')
+
+
 @pytest.mark.parametrize('tile', [0, 6, 8, 9, 10, 17, 20, 21, 22, 23, 25, 27, 29, 31])
 @pytest.mark.parametrize('split', [2, 5, 16])
 def test_gemm_split_k(split, tile):

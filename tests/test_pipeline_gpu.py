@@ -166,6 +166,42 @@ def test_config5_sd21_int8_weights_plms_matches_oracle(rig21):
     assert torch.isfinite(z).all() and r <= 2e-2, r
 
 
+def test_config5_unet_step_at_768px_uint8_weights_in_hbm(rig21):
+    """the same evaluation with weight_quant = 1: conv / linear weights STAY affine uint8 in HBM and the GEMMs stream the codes
+    (sdod_gemm_desc.wq); weight arena ~0.87 GB instead of 1.73 GB.  Same oracle, same tolerance."""
+    from sdod.amd import engine as E
+    sds, unet = rig21
+    cfg = E.sd21_config(96, 96)
+    cfg.weight_quant = 1
+    g = E.UNet(cfg, 2)
+    g.load_state_dict(sds['unet'])
+    g.finalize()
+    te = E.Temb(cfg, 1)
+    te.load_state_dict(sds['temb'])
+    te.finalize()
+    gen = torch.Generator().manual_seed(78)
+    x = torch.randn(2, 4, 96, 96, generator=gen)
+    ctx = torch.randn(2, 77, 1024, generator=gen).half()
+    te.t.copy_(torch.tensor([601.0]))
+    te.execute()
+    g.x.copy_(x); g.ctx.copy_(ctx); g.temb.copy_(te.out.expand(2, -1))
+    g.execute(True)
+    out = g.eps.float().cpu().permute(0, 3, 1, 2)
+    with torch.no_grad():
+        ref = unet(x, torch.tensor([601.0, 601.0]), ctx.float())
+    r = rel_l2(out, ref)
+    st = g.stats()
+    print('config 5 UNet step @96x96, uint8 weights in HBM: rel-L2', r, st)
+    assert torch.isfinite(out).all() and r <= 1e-2, r
+    assert st['weight_bytes'] < 0.95e9, st          # 866 M one-byte codes + fp32 vectors (fp16 build: 1.73 GB)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g.execute(True); ev0.record()
+    for _ in range(5):
+        g.execute(True, static_unchanged=True)
+    ev1.record(); torch.cuda.synchronize()
+    print('config 5 UNet step @96x96, uint8 weights: %.2f ms per replay' % (ev0.elapsed_time(ev1) / 5))
+
+
 def test_config5_unet_step_at_768px(rig21):
     """one batch-2 UNet evaluation at the full 96x96 latent of SD v2.1-768 (L = 9216 tokens at 64-wide heads)"""
     from sdod.amd import engine as E
@@ -190,3 +226,9 @@ def test_config5_unet_step_at_768px(rig21):
     r = rel_l2(out, ref)
     print('config 5 UNet step @96x96 rel-L2', r, g.stats())
     assert torch.isfinite(out).all() and r <= 1e-2, r
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g.execute(True); ev0.record()
+    for _ in range(5):
+        g.execute(True, static_unchanged=True)
+    ev1.record(); torch.cuda.synchronize()
+    print('config 5 UNet step @96x96, fp16 image of the uint8 weights: %.2f ms per replay' % (ev0.elapsed_time(ev1) / 5))

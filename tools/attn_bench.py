@@ -9,8 +9,6 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'stable-diffusion-on-device_amd')); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import torch  # noqa: E402
-from sdod.amd import ops  # noqa: E402
-from gn_bench import graph_time  # noqa: E402
 
 # (B, heads, Lq, Lk, d, count per UNet evaluation)
 SHAPES = [(2, 8, 4096, 4096, 40, 5), (2, 8, 1024, 1024, 80, 5), (2, 8, 256, 256, 160, 5), (2, 8, 64, 64, 160, 1),
@@ -19,9 +17,15 @@ SHAPES = [(2, 8, 4096, 4096, 40, 5), (2, 8, 1024, 1024, 80, 5), (2, 8, 256, 256,
 
 
 def main():
+    global ops, graph_time
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=10)
+    ap.add_argument('--lib', default='', help='developer build in lib/ to load instead of libsdod.so')
     args = ap.parse_args()
+    if args.lib:
+        os.environ['SDOD_LIBSDOD'] = args.lib
+    from sdod.amd import ops
+    from gn_bench import graph_time
     d = torch.device('cuda:0')
     tot = 0.0
     P = ctypes.c_void_p

@@ -29,9 +29,10 @@ from sdod.amd import engine as E, weights as Wt  # noqa: E402
 T0 = time.time()
 
 
-def build(cls, cfg, batch, seed, label):
+def build(cls, cfg, batch, seed, label, quant=False):
     g = cls(cfg, batch)
-    g.load_state_dict(Wt.synthetic_state_dict(g.param_table(), seed=seed))
+    sd = Wt.synthetic_state_dict(g.param_table(), seed=seed)
+    g.load_state_dict(Wt.quantize_state_dict(sd) if quant else sd)
     g.finalize()
     torch.cuda.synchronize()
     n = sum(1 for _ in open(out)) if os.path.exists(out) else 0
@@ -54,6 +55,12 @@ if not quick:
     # config 5 (SD v2.1-768) and the reduced sizes the GPU tests run
     c96 = E.sd21_config(96, 96)
     build(E.UNet, c96, 2, 2100, 'sd21 unet 96x96 b2')
+    for hw in (96, 24):      # config 5 with the weights kept uint8 in HBM (sdod_model_config.weight_quant)
+        cq = E.sd21_config(hw, hw)
+        cq.weight_quant = 1
+        build(E.UNet, cq, 2, 2100, f'sd21 unet {hw}x{hw} b2, uint8 weights', quant=True)
+        build(E.Temb, cq, 1, 2101, f'sd21 temb b1, uint8 weights', quant=True)
+        build(E.Temb, cq, 20, 2101, f'sd21 temb b20, uint8 weights', quant=True)
     build(E.VaeDecoder, c96, 1, 1236, 'vae 96x96')
     build(E.TextEncoder, c96, 2, 2102, 'openclip-H b2')
     build(E.Temb, c96, 1, 2101, 'sd21 temb b1')
