@@ -171,26 +171,55 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
     for (int t = 0; t < NT; ++t) {
         const int cur = t & 1;
         const bool has_next = t + 1 < NT;
-        if (has_next && !(abl & 1)) load_tile(t + 1);
 
         const f16* sK = smem + cur * STAGE;
         const f16* sV = sK + KT * KSTR;
 
-        // ---- S^T = K . Q^T
+        // ---- fragments of the tile first: K for S^T = K . Q^T and (transposed) V for O^T += V^T . P^T are read ONCE and kept
+        // in registers for both query tiles; the V reads are issued here so that they land during the softmax
+        // (D = 160 would need 160 registers for them and drop to one wave per SIMD: it reads at the point of use)
+        constexpr bool HOLD = D <= 80;
+        f16x8 kf[HOLD ? KSTEPS : 1][4];
+        if (HOLD) {
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) kf[ks][c] = *reinterpret_cast<const f16x8*>(sK + (c * 16 + li) * KSTR + ks * 32 + g * 8);
+        }
+        f16x8 vfr[HOLD ? 2 : 1][HOLD ? NDT : 1];
+        auto read_vt = [&](int u, int dt) -> f16x8 {
+            const f16* a0 = sV + (32 * u + 4 * g + (li >> 2)) * VSTR + dt * 16 + 4 * (li & 3);
+            const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(a0));
+            const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(a0 + 16 * VSTR));
+            typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
+            const short8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            return __builtin_bit_cast(f16x8, both);
+        };
+        if (TR && HOLD) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) vfr[u][dt] = read_vt(u, dt);
+        }
+        // ---- S^T = K . Q^T, query tile by query tile: the softmax of tile a starts (VALU) while the matrix pipe is still
+        // busy with tile a + 1, and further down the PV product of tile a runs under the softmax of tile a + 1
         f32x4 s[QT][4];
 #pragma unroll
-        for (int a = 0; a < QT; ++a)
+        for (int a = 0; a < QT; ++a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) s[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
+            for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f16x8 kf = *reinterpret_cast<const f16x8*>(sK + (c * 16 + li) * KSTR + ks * 32 + g * 8);
-#pragma unroll
-                for (int a = 0; a < QT; ++a) s[a][c] = mfma16(kf, qf[a][ks], s[a][c]);
-            }
+                for (int c = 0; c < 4; ++c) {
+                    const f16x8 k8 = HOLD ? kf[ks][c] : *reinterpret_cast<const f16x8*>(sK + (c * 16 + li) * KSTR + ks * 32 + g * 8);
+                    s[a][c] = mfma16(k8, qf[a][ks], s[a][c]);
+                }
         }
+        // the next tile's K/V are requested HERE, behind the fragment reads and the QK^T issue: requested at the top of the
+        // iteration, the compiler's wait-count pass (it cannot count loads under divergent predicates) put a vmcnt(0) in front
+        // of the first MFMA, i.e. the full global-load latency on the critical path of every tile
+        if (has_next && !(abl & 1)) load_tile(t + 1);
 
         // ---- online softmax; lane owns query qrow[a], keys t*64 + c*16 + 4g + r.
         // VALU budget matters here (at d=40 the MFMAs of a tile take ~450 cycles, a naive softmax 3x that): the row max is
@@ -210,13 +239,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
                         s[a][c][r] = masked ? -1e30f : s[a][c][r];
                     }
             }
-            f32x4 m4 = s[a][0];
+            // row maximum of this lane's 16 scores as a chain of three-input maxima (v_max3_f32: 8 instructions instead of 15)
+            float mx = fmaxf(fmaxf(s[a][0][0], s[a][0][1]), s[a][0][2]);
+            mx = fmaxf(fmaxf(mx, s[a][0][3]), s[a][1][0]);
 #pragma unroll
             for (int c = 1; c < 4; ++c) {
-                m4[0] = fmaxf(m4[0], s[a][c][0]); m4[1] = fmaxf(m4[1], s[a][c][1]);
-                m4[2] = fmaxf(m4[2], s[a][c][2]); m4[3] = fmaxf(m4[3], s[a][c][3]);
+                mx = fmaxf(fmaxf(mx, s[a][c][1]), s[a][c][2]);
+                if (c < 3) mx = fmaxf(fmaxf(mx, s[a][c][3]), s[a][c + 1][0]);
+                else mx = fmaxf(mx, s[a][c][3]);
             }
-            float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float m_new = fmaxf(m_run[a], mx * p.scale_log2); // running max in scaled (log2) units
@@ -263,29 +294,23 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
                 }
                 pf[a][u] = f;
             }
-        }
-
-        // ---- O^T += V^T . P^T ; contraction element e of lane group g is key 32u + 16(e>>2) + 4g + (e&3)
+            // ---- O^T += V^T . P^T for this query tile; contraction element e of lane group g is key 32u + 16(e>>2) + 4g + (e&3)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < 2; ++u) {
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                f16x8 vf;
-                if (TR) {
-                    const f16* a0 = sV + (32 * u + 4 * g + (li >> 2)) * VSTR + dt * 16 + 4 * (li & 3);
-                    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(a0));
-                    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(a0 + 16 * VSTR));
-                    typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
-                    const short8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    vf = __builtin_bit_cast(f16x8, both);
-                } else {
+                for (int dt = 0; dt < NDT; ++dt) {
+                    f16x8 vf;
+                    if (TR) {
+                        vf = HOLD ? vfr[u][dt] : read_vt(u, dt);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) vf[e] = sV[(32 * u + 16 * (e >> 2) + 4 * g + (e & 3)) * VSTR + dt * 16 + li];
+                        for (int e = 0; e < 8; ++e) vf[e] = sV[(32 * u + 16 * (e >> 2) + 4 * g + (e & 3)) * VSTR + dt * 16 + li];
+                    }
+                    o[a][dt] = mfma16(vf, pf[a][u], o[a][dt]);
                 }
-#pragma unroll
-                for (int a = 0; a < QT; ++a) o[a][dt] = mfma16(vf, pf[a][u], o[a][dt]);
             }
         }
+
 
         if (has_next) store_tile(cur ^ 1);
         __syncthreads();
@@ -325,12 +350,11 @@ hipError_t attn_launch(const AttnP& p, hipStream_t st) {
     constexpr int DP = ((D + 31) / 32) * 32;
     constexpr int DV = ((D + 15) / 16) * 16;
     constexpr size_t smem = (size_t)2 * 64 * (DP + 8 + odd16(DV)) * sizeof(f16);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_devs{0};
+    if (sdod::first_use_on_device(attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, QT, TR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     dim3 grid(((p.Lq + 64 * QT - 1) / (64 * QT)) * p.H * p.B);
     hipLaunchKernelGGL((attn_kernel<D, QT, TR>), grid, dim3(256), smem, st, p);
@@ -363,7 +387,8 @@ extern "C" int sdod_attention_f16(const void* q, const void* k, const void* v, v
     p.causal = causal;
     const bool no_tr = std::getenv("SDOD_ATTN_NO_TR") != nullptr; // debugging aid: scalar LDS reads instead of ds_read_b64_tr_b16
     const bool tr = !no_tr;
-    const bool big = lq >= 2048 && d != 160; // two query tiles per wave once there is enough work to fill the chip
+    bool big = lq >= 2048 && d != 160; // two query tiles per wave once there is enough work to fill the chip
+    if (const char* e = std::getenv("SDOD_ATTN_QT")) big = e[0] == '2' && d != 160; // developer override (tools/attn_bench.py)
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
     switch (d) {

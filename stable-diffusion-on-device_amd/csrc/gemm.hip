@@ -1049,13 +1049,19 @@ const TileCfg kTiles[] = {{0, 0},     {128, 128}, {128, 64}, {64, 64},   {256, 1
                           {128, 128}, {128, 128}, {128, 256}, {256, 128}, {64, 64}, {64, 64}, {128, 64}, {64, 128}, {64, 160}};
 constexpr int kNumTiles = 31;
 
-const f16* zero_line() {
-    static f16* z = nullptr;
-    if (!z) {
-        if (hipMalloc((void**)&z, 1024) != hipSuccess) return nullptr;
-        (void)hipMemset(z, 0, 1024);
+const f16* zero_line() { // one per device (the pointer is only valid on the device that allocated it)
+    static std::atomic<f16*> z[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    f16* cur = z[dev].load(std::memory_order_acquire);
+    if (!cur) {
+        f16* fresh = nullptr;
+        if (hipMalloc((void**)&fresh, 1024) != hipSuccess) return nullptr;
+        (void)hipMemset(fresh, 0, 1024);
+        if (z[dev].compare_exchange_strong(cur, fresh, std::memory_order_acq_rel)) cur = fresh;
+        else (void)hipFree(fresh); // another thread won the race
     }
-    return z;
+    return cur;
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, bool SPEC = false, bool WQ = false>
@@ -1063,12 +1069,11 @@ hipError_t launch_glds(const GemmP& p, dim3 grid, hipStream_t st) {
     constexpr size_t ring = (size_t)STAGES * (BM + BN) * 64 * sizeof(f16);
     constexpr size_t ctile = (size_t)BM * (BN + 8) * sizeof(f16) + (size_t)BM * 2 * sizeof(float); // + LayerNorm row stats
     constexpr size_t smem = (ring > ctile ? ring : ctile) + (size_t)4 * BN * sizeof(float); // + per-column epilogue vectors
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_devs{0};
+    if (sdod::first_use_on_device(attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, STAGES, SPEC, WQ>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const f16* z = zero_line();
     if (!z) return hipErrorOutOfMemory;
@@ -1079,12 +1084,11 @@ hipError_t launch_glds(const GemmP& p, dim3 grid, hipStream_t st) {
 template <int BM, int BN, int WM, int WN>
 hipError_t launch_cfg(const GemmP& p, dim3 grid, hipStream_t st) {
     constexpr size_t smem = (size_t)2 * (BM + BN) * 64 * sizeof(f16);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_devs{0};
+    if (sdod::first_use_on_device(attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WM, WN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), grid, dim3(256), smem, st, p);
     return hipGetLastError();

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <stdexcept>
 #include <string>
 
@@ -24,6 +25,15 @@ struct Error : std::runtime_error {
 
 void set_last_error(const std::string& msg);
 const char* get_last_error();
+
+// Kernel attributes (dynamic LDS size) are per device: true the first time the calling thread's CURRENT device meets the
+// call site owning `mask` (one bit per device ordinal; two threads racing both set the attribute, which is idempotent).
+inline bool first_use_on_device(std::atomic<unsigned long long>& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    const unsigned long long bit = 1ull << dev;
+    return (mask.fetch_or(bit, std::memory_order_relaxed) & bit) == 0;
+}
 
 } // namespace sdod
 

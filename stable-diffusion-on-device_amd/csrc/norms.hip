@@ -450,7 +450,9 @@ __global__ __launch_bounds__(NT) void gn_group_kernel(const GnG p) {
                 for (int e = 0; e < V; ++e) acc[k][e] = 0.f;
             // U slabs are requested before the first is summed (a one-slab-at-a-time loop pays a full memory round trip per
             // split); the sums are still taken in ascending split order, as splitk_reduce_kernel does (+0 for the tail slots)
-            constexpr int U = KMAX * V <= 8 ? 4 : KMAX * V <= 16 ? 2 : 1; // <= 32 staged floats per thread
+            // staged floats per thread: 128 in a 256-thread workgroup (512 registers per thread available), 64 at 1024 threads
+            constexpr int UB = (NT == 256 ? 128 : KMAX <= 2 ? 64 : 32) / (KMAX * V);
+            constexpr int U = UB >= 8 ? 8 : UB >= 4 ? 4 : UB >= 2 ? 2 : 1;
             for (int s0 = 0; s0 < p.r.splits; s0 += U) {
                 FloatVec<V> t[U][KMAX];
 #pragma unroll
@@ -647,11 +649,10 @@ static bool gn_small_fits(int hw, int c, int cg, size_t elem) {
 
 template <typename T, int NT>
 void gn_small_launch(GnP& p, int sw, size_t smem, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_devs{0};
+    if (sdod::first_use_on_device(attr_devs)) {
         SDOD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<T, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            96 * 1024 + 4096));
-        attr_set = true;
     }
     hipLaunchKernelGGL((gn_small_kernel<T, NT>), dim3(p.C / sw, p.N), dim3(NT), smem, st, p, sw);
     SDOD_HIP_CHECK(hipGetLastError());

@@ -11,8 +11,12 @@ What differs, on purpose:
     csrc/sdod_ops/config/group_norm.{xml,json} but never ships.  If the HIP library is missing this
     raises -- there is no silent fallback on a GPU tensor.  CPU tensors (ONNX export, CPU tests) use
     F.group_norm exactly as the reference's forward does (:11-12).
-  * impl='ln'/'bn' apply the affine parameters (reference quirk Q1, :84-85 has it commented out, so
-    its own tests/gn_to_ln.py prints False for them); with identity affine the results are identical.
+    Shapes / dtypes outside the kernel's domain (channels not a multiple of 8, more than 4096 channels, bf16 / fp64)
+    take F.group_norm on the device, as the reference's forward would -- a stated domain limit, not an error fallback.
+  * impl='ln'/'bn' reproduce the reference bit for bit by default, INCLUDING its quirk Q1: the affine parameters are not
+    applied (:84-85 has that code commented out, so the reference's own tests/gn_to_ln.py prints False for them; pinned by
+    tests/golden/gn_efficient.npz), and 'bn' divides by sqrt(1 + eps) without normalising (eval-mode batch_norm against
+    running statistics (0, 1), :71-76).  `fix_affine=True` (extra) makes both equal nn.GroupNorm (normalise + affine).
   * `fuse_silu=True` (extra, default False) fuses the SiLU that follows every ResBlock GroupNorm.
 """
 from functools import reduce
@@ -25,6 +29,10 @@ import torch.nn.functional as F
 
 def _hip_group_norm(x, num_groups, weight, bias, eps, silu=False):
     from .amd import ops  # raises loudly if lib/libsdod.so is not built
+    c = x.shape[1]
+    if x.dtype not in (torch.float16, torch.float32) or c % 8 != 0 or c > 4096 or x.numel() == 0:
+        y = F.group_norm(x, num_groups, weight, bias, eps)       # outside the kernel's domain (see module docstring)
+        return F.silu(y) if silu else y
     return ops.group_norm_nchw(x, num_groups, weight, bias, eps, silu)
 
 
@@ -58,7 +66,7 @@ def efficient_group_norm(input, num_groups, weight=None, bias=None, eps=1e-5):
 
 class EfficientGN(nn.Module):
     def __init__(self, num_groups: int, num_channels: int, eps: float = 1e-5, affine: bool = True, device=None,
-                 dtype=None, impl=None, fuse_silu: bool = False) -> None:
+                 dtype=None, impl=None, fuse_silu: bool = False, fix_affine: bool = False) -> None:
         super().__init__()
         if num_channels % num_groups != 0:
             raise ValueError('num_channels must be divisible by num_groups')
@@ -70,6 +78,7 @@ class EfficientGN(nn.Module):
         self.affine = affine
         self.impl = impl
         self.fuse_silu = fuse_silu
+        self.fix_affine = fix_affine
         if affine:
             self.weight = nn.Parameter(torch.empty(num_channels, device=device, dtype=dtype))
             self.bias = nn.Parameter(torch.empty(num_channels, device=device, dtype=dtype))
@@ -84,7 +93,7 @@ class EfficientGN(nn.Module):
             nn.init.zeros_(self.bias)
 
     def _affine(self, y):
-        if not self.affine:
+        if not self.affine or not self.fix_affine:      # reference behaviour (quirk Q1): 'ln' / 'bn' drop weight and bias
             return y
         bshape = (1, self.num_channels) + (1,) * (y.dim() - 2)
         return y * self.weight.reshape(bshape) + self.bias.reshape(bshape)
@@ -106,8 +115,17 @@ class EfficientGN(nn.Module):
             y = F.layer_norm(y, (cpg * spatial,), None, None, eps=self.eps)
             out = self._affine(y.reshape(shape))
         elif self.impl == 'bn':
-            y = input.reshape(1, shape[0] * self.num_groups, cpg * spatial)
-            y = F.batch_norm(y, None, None, None, None, training=True, momentum=0.0, eps=self.eps)
+            if self.fix_affine:
+                y = input.reshape(1, shape[0] * self.num_groups, cpg * spatial)
+                y = F.batch_norm(y, None, None, None, None, training=True, momentum=0.0, eps=self.eps)
+            else:
+                # the reference's arithmetic (:71-76): eval-mode batch_norm against running statistics (0, 1), i.e.
+                # x / sqrt(1 + eps) -- it never normalises; kept for drop-in fidelity, pinned by the golden file
+                y = input.reshape(shape[0] * self.num_groups, cpg, spatial).permute(1, 0, 2)
+                ng = shape[0] * self.num_groups
+                y = F.batch_norm(y, torch.zeros(ng, dtype=input.dtype, device=input.device), torch.ones(ng, dtype=input.dtype, device=input.device),
+                                 None, None, training=False, momentum=0, eps=self.eps)
+                y = y.permute(1, 0, 2)
             out = self._affine(y.reshape(shape))
         else:
             raise NotImplementedError(self.impl)
