@@ -665,7 +665,12 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
         pending_.d = d2;
         pending_.bytes = part + (double)d.M * d.N * 2 * (d.residual ? 2 : 1);
         pending_.detail = detail;
-        if (to_static_ || std::getenv("SDOD_NO_GN_REDUCE")) flush_pending();
+        // Measured on MI355X inside a replay (tools/gn_bench.py, profiles/r02_gn_bench.txt): the stand-alone reduce costs
+        // 3.2-4.1 us and the one-launch GroupNorm 4.3-8.2 us, the fused form 7.6-16 us -- its 64 (image, group) workgroups
+        // read the fp32 slabs with a quarter of the chip -- so fusing LOSES 0-3.7 us per site.  The deferral is therefore off
+        // unless SDOD_GN_REDUCE=1 (kept, with its kernel and tests, for shapes where the balance differs).
+        static const bool fuse_reduce = [] { const char* e = std::getenv("SDOD_GN_REDUCE"); return e && e[0] == '1'; }();
+        if (to_static_ || !fuse_reduce) flush_pending();
         return;
     }
     sink().push_back(Op{[d](hipStream_t st) { check_rc(sdod_gemm_f16(&d, st)); }, label, fl, by, detail});

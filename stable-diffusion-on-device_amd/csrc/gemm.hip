@@ -1108,7 +1108,8 @@ Plan make_plan(const sdod_gemm_desc* d) {
     const bool fused = d->geglu || d->k_tail || d->ln || d->wq;
     if (fused && (tile < 6 || tile > kNumTiles)) tile = 14; // fusions live in the LDS-DMA kernel family only
     if (d->geglu && (tile == 21 || tile == 22 || tile == 31)) tile = 14;
-    if (d->wq && !(tile == 8 || tile == 13 || tile == 23 || tile == 24 || (tile >= 27 && tile <= 30))) tile = 23; // uint8-weight variants  // value/gate pairing needs an even number of 16-column blocks per wave
+    if (d->wq && !(tile == 8 || tile == 13 || tile == 23 || tile == 24 || (tile >= 27 && tile <= 31))) tile = 23; // uint8-weight variants
+    if (d->wq && d->geglu && tile == 31) tile = 23;  // value/gate pairing needs an even number of 16-column blocks per wave
     if (tile <= 0 || tile > kNumTiles) {
         if (d->N <= 16) {
             tile = 4;
@@ -1301,6 +1302,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     case 28: e = launch_glds<64, 64, 2, 2, 4, true, true>(p, grid, st); break;
     case 29: e = launch_glds<128, 64, 2, 2, 6, true, true>(p, grid, st); break;
     case 30: e = launch_glds<64, 128, 2, 2, 6, true, true>(p, grid, st); break;
+    case 31: e = launch_glds<64, 160, 2, 2, 4, true, true>(p, grid, st); break;
     default: e = launch_glds<128, 128, 2, 2, 4, true, true>(p, grid, st); break; // 23
     }
     else if (d->phase != 2)

@@ -53,6 +53,24 @@ def main():
         tot += us * cnt
         print(f'n{n} hw{hw:6d} c{c:5d}         {lib.sdod_group_norm_launches(hw, c, 32, 0):8d} {us:8.2f} {by / us / 1e3:8.1f} {us * cnt:8.1f}', flush=True)
     print(f'sum over one UNet evaluation: {tot / 1e3:.3f} ms')
+    # GroupNorm with the producing conv's split-K reduce folded in (sdod_group_norm_reduce_nhwc) next to the two launches
+    # it replaces (splitk_reduce + GroupNorm); (n, side, cin, cout, splits, count per UNet evaluation)
+    print(f'\n{"fused reduce + GroupNorm":34s} {"fused us":>9s} {"reduce us":>10s} {"gn us":>8s}')
+    for n, side, cin, cout, split, cnt in [(2, 32, 640, 640, 3, 10), (2, 16, 1280, 1280, 6, 10), (2, 8, 1280, 1280, 6, 11), (2, 32, 320, 320, 3, 1)]:
+        hw = side * side
+        x = torch.randn(n, side, side, cin).half().to(d)
+        wt = (torch.randn(cout, 9 * cin) * (9 * cin) ** -0.5).half().to(d)
+        bias = torch.randn(cout).to(d)
+        temb = torch.randn(n, cout).half().to(d)
+        gw = torch.randn(cout).to(d); gb = torch.randn(cout).to(d)
+        kw = dict(row_bias=temb, rows_per_img=hw, conv=dict(stride=1), split_k=split, tile=28)
+        out, desc = ops.gemm(x, wt, bias, phase=1, return_desc=True, **kw)
+        fused = graph_time(lambda: ops.group_norm_reduce(desc, n, hw, 32, gw, gb, 1e-5, True), args.reps)
+        desc2 = type(desc).from_buffer_copy(desc); desc2.phase = 2
+        red = graph_time(lambda: _lib.check(lib.sdod_gemm_f16(__import__('ctypes').byref(desc2), ops._stream())), args.reps)
+        y = torch.empty(n, hw, cout, dtype=torch.float16, device=d)
+        gn = graph_time(lambda: ops.group_norm_nhwc(out.reshape(n, hw, cout), 32, gw, gb, 1e-5, True, out=y), args.reps)
+        print(f'n{n} hw{hw:5d} c{cout:5d} x{split}              {fused:9.2f} {red:10.2f} {gn:8.2f}   (x{cnt})', flush=True)
 
 
 if __name__ == '__main__':
