@@ -54,22 +54,23 @@ def host_threads():
     return max(1, min(16, n))
 
 
-# launch-list label -> kernel symbol as rocprofv3 prints it (tile table in csrc/gemm.hip)
-KERNEL_SYMBOLS = {
-    'gemm_t1': 'gemm_kernel<128, 128, 2, 2>', 'gemm_t2': 'gemm_kernel<128, 64, 2, 2>', 'gemm_t3': 'gemm_kernel<64, 64, 2, 2>',
-    'gemm_t4': 'gemm_kernel<256, 16, 4, 1>', 'gemm_t5': 'gemm_kernel<64, 128, 2, 2>',
-    'gemm_t6': 'gemm_glds_kernel<128, 128, 2, 2, 3>', 'gemm_t7': 'gemm_glds_kernel<128, 64, 2, 2, 4>',
-    'gemm_t8': 'gemm_glds_kernel<64, 64, 2, 2, 4>', 'gemm_t9': 'gemm_glds_kernel<128, 128, 2, 4, 3>',
-    'gemm_t10': 'gemm_glds_kernel<256, 128, 4, 2, 2>', 'gemm_t11': 'gemm_glds_kernel<128, 64, 4, 2, 4>',
-    'gemm_t12': 'gemm_glds_kernel<256, 64, 4, 2, 3>', 'gemm_t13': 'gemm_glds_kernel<128, 128, 2, 4, 4>',
-    'gemm_t14': 'gemm_glds_kernel<128, 128, 2, 4, 2>', 'gemm_t15': 'gemm_glds_kernel<256, 128, 4, 2, 3>',
-    'gemm_t16': 'gemm_glds_kernel<256, 256, 2, 4, 2>', 'gemm_t17': 'gemm_glds_kernel<64, 64, 2, 2, 8>',
-    'gemm_t18': 'gemm_glds_kernel<128, 64, 2, 2, 6>', 'gemm_t19': 'gemm_glds_kernel<64, 128, 2, 2, 6>',
-    'gemm_t20': 'gemm_glds_kernel<128, 256, 2, 4, 3>', 'gemm_t21': 'gemm_glds_kernel<64, 160, 2, 2, 4>',
-    'gemm_t22': 'gemm_glds_kernel<32, 160, 2, 2, 6>', 'gn_small': 'gn_small_kernel<f16>',
-    'gn_stats_apply': 'gn_stats_kernel<f16, 1> + gn_apply_kernel<f16>', 'splitk_reduce': 'splitk_reduce_kernel', 'attn_d40': 'attn_kernel<40, 2, true>',
-    'attn_d80': 'attn_kernel<80, 1, true>', 'attn_d160': 'attn_kernel<160, 1, true>',
-}
+def kernel_symbol(label):
+    """launch-list label -> (kernel symbol as rocprofv3 prints it, fragment of its mangled name or None).  GEMM labels carry
+    the tile id; its template arguments come from the library (sdod_gemm_tile_info), so the table cannot go stale."""
+    import ctypes
+    from sdod.amd import _lib
+    if label.startswith('gemm_t'):
+        info = (ctypes.c_int * 7)()
+        if _lib.hip().sdod_gemm_tile_info(int(label[6:]), info) == 0:
+            bm, bn, wm, wn, st, spec, ksub = list(info)
+            if st == 0:
+                return f'gemm_kernel<{bm}, {bn}, {wm}, {wn}>', f'gemm_kernelILi{bm}ELi{bn}ELi{wm}ELi{wn}EE'
+            return (f'gemm_glds_kernel<{bm}, {bn}, {wm}, {wn}, {st}, {"true" if spec else "false"}, false, {ksub}>',
+                    f'gemm_glds_kernelILi{bm}ELi{bn}ELi{wm}ELi{wn}ELi{st}ELb{spec}ELb0ELi{ksub}EE')
+    plain = {'gn_group': 'gn_group_kernel<', 'gn_group_red': 'gn_group_kernel<', 'gn_stats_apply': 'gn_stats_kernel<', 'splitk_reduce': 'splitk_reduce_kernel',
+             'attn_d40': 'attn_kernel<40,', 'attn_d64': 'attn_kernel<64,', 'attn_d80': 'attn_kernel<80,', 'attn_d160': 'attn_kernel<160,',
+             'layer_norm': 'layer_norm_kernel', 'softmax_rows': 'softmax_rows_kernel<'}
+    return plain.get(label, label), None
 
 
 def parse():
@@ -232,13 +233,20 @@ def main():
         # ---- roofline of the dominant kernel family: per-launch HIP events over the UNet launch list (eager, same stream)
         log(f'per-UNet-step {unet_step_ms:.3f} ms; profiling the launch list')
         table = pipe.unet.op_table()
-        ms = pipe.unet.profile(iters=3)
-        # one family per KERNEL SYMBOL: every launch-list entry is exactly one kernel (a split-K GEMM is two entries, the
-        # GEMM proper and `splitk_reduce`), so the per-launch average is comparable with rocprofv3's per-symbol average
+        ms = pipe.unet.profile(iters=5)
+        # Durations are the kernels' own begin-to-end times (Graph::profile launches every entry through
+        # hipExtLaunchKernelGGL with a start / stop event pair: what a profiler reports per dispatch).  One family per KERNEL
+        # SYMBOL over everything ONE IMAGE launches -- 21 UNet evaluations + the VAE decode + the text encoder -- i.e. the
+        # population behind rocprofv3's per-symbol average for this very command (profiles/*_kernel_stats.csv).
         fam = {}
-        for (label, fl, by), t in zip(table, ms):
-            f = fam.setdefault(label, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-            f['ms'] += t; f['flops'] += fl; f['bytes'] += by; f['launches'] += 1
+        per_image = [(pipe.unet, table, ms, 21)]
+        for g in (pipe.vae, pipe.text):
+            if g is not None:
+                per_image.append((g, g.op_table(), g.profile(iters=3), 1))
+        for _, tab, tms, reps in per_image:
+            for (label, fl, by), t in zip(tab, tms):
+                f = fam.setdefault(label, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+                f['ms'] += t * reps; f['flops'] += fl * reps; f['bytes'] += by * reps; f['launches'] += reps
         # per-shape table (label, shape, launches per evaluation, us each, TF/s, GB/s): printed on stderr and carried in
         # the JSON line, so BENCH, the rocprofv3 CSV and the PMC passes can be compared shape by shape
         details = pipe.unet.op_details()
@@ -249,11 +257,12 @@ def main():
         shape_rows = [[lab, det, r[0], round(1e3 * r[1] / r[0], 2), round(r[2] / (r[1] * 1e-3) / 1e12, 1) if r[2] else None,
                        round(r[3] / (r[1] * 1e-3) / 1e9, 1) if r[3] else None]
                       for (lab, det), r in sorted(shapes.items(), key=lambda kv: -kv[1][1])]
-        log('UNet launch list by shape (eager, HIP events):\n' + '\n'.join(
+        log('UNet launch list by shape (kernel begin-to-end, per evaluation):\n' + '\n'.join(
             f'  {lab:16s} {det:44s} x{n:<3d} {us:8.2f} us  {str(tf):>7s} TF/s  {str(gb):>8s} GB/s' for lab, det, n, us, tf, gb in shape_rows))
         dom = max(fam, key=lambda k: fam[k]['ms'])
         d = fam[dom]
         total_ms = sum(ms)
+        image_kernel_ms = sum(f['ms'] for f in fam.values())
         if d['flops'] > 0:
             ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
             roof = dict(bound='mfma', achieved=round(ach, 2), peak=PEAK_TFLOPS_F16, unit='TFLOP/s', frac=round(ach / PEAK_TFLOPS_F16, 4),
@@ -266,24 +275,22 @@ def main():
         # picks, tools/run_profile.sh + tools/pmc_summary.py apply the guide's gfx950 corrections); `traffic_source` says so,
         # and the fields stay null when no committed measurement matches the dominant symbol
         try:
-            import re
-            sym = KERNEL_SYMBOLS.get(dom, dom)
-            nums = re.findall(r'\d+', sym)
-            mangled = ''.join(f'Li{n}E' for n in nums) if sym.startswith('gemm_glds_kernel') else None
+            sym, mangled = kernel_symbol(dom)
             pmc_file = os.path.join('profiles', PMC_SUMMARY)
             for k in json.load(open(os.path.join(ROOT, pmc_file)))['kernels']:
                 name = k['kernel']
-                if (mangled and 'gemm_glds_kernel' in name and ('I' + mangled + 'E') in name) or (not mangled and sym in name):
+                if (mangled and mangled in name) or (not mangled and sym in name):
                     roof['traffic'] = k['hbm_fetch_bytes_per_launch'] + k['hbm_write_bytes_per_launch']
                     roof['mfma_util_pmc'] = k['mfma_util']
                     roof['traffic_source'] = f'offline: {pmc_file} (separate rocprofv3 --pmc passes, not measured in this run)'
                     break
         except (OSError, ValueError, KeyError, TypeError):
             pass
-        roof.update(kernel=dom, kernel_symbol=KERNEL_SYMBOLS.get(dom, dom),
+        roof.update(kernel=dom, kernel_symbol=kernel_symbol(dom)[0],
                     flops_per_launch=round(d['flops'] / d['launches']), algorithmic_bytes_per_launch=round(d['bytes'] / d['launches']),
-                    launches_per_unet_eval=d['launches'], avg_launch_us=round(1e3 * d['ms'] / d['launches'], 2),
-                    share_of_unet_eval=round(d['ms'] / total_ms, 3), unet_eval_eager_ms=round(total_ms, 3),
+                    launches_per_image=d['launches'], avg_launch_us=round(1e3 * d['ms'] / d['launches'], 2),
+                    share_of_image_kernel_time=round(d['ms'] / image_kernel_ms, 3), image_kernel_ms=round(image_kernel_ms, 2),
+                    unet_eval_kernel_ms=round(total_ms, 3), timing='kernel begin-to-end (hipExtLaunchKernelGGL start/stop events), per image: 21 UNet evaluations + VAE decode + text encoder',
                     launches_per_unet_eval_total=len(table), tune_table=pipe.unet.tune_source(),
                     unet_eval_tflops=round(pipe.unet.stats()['flops'] / (unet_step_ms * 1e-3) / 1e12, 1),
                     families={k: dict(ms=round(v['ms'], 3), launches=v['launches'],

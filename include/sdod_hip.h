@@ -110,6 +110,8 @@ SDOD_API int sdod_gemm_plan(const sdod_gemm_desc* d, int* tile, int* splits);
 SDOD_API int sdod_gemm_num_tiles(void);
 /* rows x columns of tile configuration `tile`; lds_dma = 1 for the LDS-DMA kernel family (tiles >= 6) */
 SDOD_API int sdod_gemm_tile_shape(int tile, int* bm, int* bn, int* lds_dma);
+/* template arguments of the kernel behind `tile`: {BM, BN, WM, WN, STAGES (0: register-staged gemm_kernel), SPEC, KSUB} */
+SDOD_API int sdod_gemm_tile_info(int tile, int out[7]);
 /* developer aid: average duration in ms of `iters` back-to-back launches (HIP events on `stream`) */
 SDOD_API int sdod_gemm_time(const sdod_gemm_desc* d, void* stream, int iters, float* ms_avg);
 /* Same, with cold caches: before every timed launch a sweep of `scratch` (>= 64 MiB; use >= 512 MiB to clear the 256 MiB

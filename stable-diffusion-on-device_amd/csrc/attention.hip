@@ -357,7 +357,7 @@ hipError_t attn_launch(const AttnP& p, hipStream_t st) {
         if (e != hipSuccess) return e;
     }
     dim3 grid(((p.Lq + 64 * QT - 1) / (64 * QT)) * p.H * p.B);
-    hipLaunchKernelGGL((attn_kernel<D, QT, TR>), grid, dim3(256), smem, st, p);
+    SDOD_LAUNCH((attn_kernel<D, QT, TR>), grid, dim3(256), smem, st, p);
     return hipGetLastError();
 }
 

@@ -351,7 +351,7 @@ __global__ void randn_kernel(float* out, uint32_t* words, size_t count, uint64_t
 
 #define LAUNCH(kernel, work, st, ...)                                                            \
     do {                                                                                         \
-        hipLaunchKernelGGL(kernel, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)(st), __VA_ARGS__); \
+        SDOD_LAUNCH(kernel, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)(st), __VA_ARGS__); \
         SDOD_HIP_CHECK(hipGetLastError());                                                       \
     } while (0)
 
@@ -440,8 +440,8 @@ extern "C" int sdod_timestep_features_f16(const float* t, void* y, int n, int di
 extern "C" int sdod_softmax_rows_f16(const void* x, void* y, int m, int n, void* stream) {
     SDOD_TRY
     SDOD_REQUIRE(x && y && m > 0 && n > 0 && n % 8 == 0 && n <= 16384, "softmax rows need N % 8 == 0 and N <= 16384");
-    if (n <= 8192) hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3(m), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, m, n);
-    else hipLaunchKernelGGL(softmax_rows_kernel<8>, dim3(m), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, m, n);
+    if (n <= 8192) SDOD_LAUNCH(softmax_rows_kernel<4>, dim3(m), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, m, n);
+    else SDOD_LAUNCH(softmax_rows_kernel<8>, dim3(m), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, m, n);
     SDOD_HIP_CHECK(hipGetLastError());
     return 0;
     SDOD_CATCH

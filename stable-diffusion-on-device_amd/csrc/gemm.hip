@@ -391,7 +391,9 @@ SDOD_DEVICE f16x8 wq_frag(const f16* sB, int row, int ks, int fc) {
 // measured, tools/gemm_phases.py); with the roles split they overlap between the same barriers.
 // WQ = the weight operand is affine uint8 (GemmP::wq): a compile-time variant, so that the fp16 kernels carry none of its code
 // or registers (several sit exactly at the 128-register step that lets two workgroups share a CU).
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPEC = false, bool WQ = false>
+// KSUB = slabs per barrier: the ring holds STAGES groups of KSUB slabs and the workgroup synchronises once per GROUP (the
+// counted wait + barrier + loop bookkeeping of a 64-deep slab cost ~0.15 us, a third of a 64x64 tile's slab time).
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPEC = false, bool WQ = false, int KSUB = 1>
 __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kernel(const GemmP p, const f16* __restrict__ zeros) {
     constexpr int NC = WM * WN;                   // waves that own output tiles
     constexpr int NW = SPEC ? 2 * NC : NC;        // waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD)
@@ -404,7 +406,9 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
     constexpr int STAGE = (BM + BN) * 64;         // halves per slab
     constexpr int SC = BN + 8;
     static_assert((NW == 4 || NW == 8) && BM % (8 * NL) == 0 && BN % (8 * NL) == 0 && TM >= 1 && TN >= 1, "tile shape");
-    static_assert(LOADS * (STAGES - 1) < 64, "vmcnt is a 6-bit counter");
+    static_assert(LOADS * (STAGES - 1) * KSUB < 64, "vmcnt is a 6-bit counter");
+    constexpr int NSLOT = STAGES * KSUB;          // slabs in the ring
+    constexpr int AHEAD = (STAGES - 1) * KSUB;    // prefetch distance in slabs
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f16* smem = reinterpret_cast<f16*>(smem_raw);
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
     // per-column epilogue vectors (bias, bias2, LayerNorm-fold s) -> LDS by LDS-DMA (4 bytes per lane, no VGPR round trip, no
     // wait): issued BEFORE the first slab, so they are older than every slab and have landed when the first counted wait of
     // the main loop returns; the epilogue then has no dependent global loads.  Absent vectors / columns past N read the zero line.
-    constexpr size_t RING_BYTES = (size_t)STAGES * STAGE * sizeof(f16);
+    constexpr size_t RING_BYTES = (size_t)NSLOT * STAGE * sizeof(f16);
     constexpr size_t CTILE_BYTES = (size_t)BM * SC * sizeof(f16) + (size_t)BM * 2 * sizeof(float);
     float* colv = reinterpret_cast<float*>(smem_raw + (RING_BYTES > CTILE_BYTES ? RING_BYTES : CTILE_BYTES)); // [4][BN]
     {
@@ -653,14 +657,17 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) rs1[i] = rs2[i] = 0.f;
 #pragma unroll
-            for (int s = 0; s < STAGES - 1; ++s)
+            for (int s = 0; s < AHEAD; ++s)
                 if (s < nkt) issue_tile(kt_begin + s, s);
             STAMP(1);
             for (int it = 0; it < nkt; ++it) {
-                wait_younger<LOADS, STAGES - 2>(nkt - 1 - it); // slab `it` of THIS wave has landed ...
-                __builtin_amdgcn_s_barrier();                  // ... and everybody's; slab it-1 is no longer read
-                if (p.ln || WQ) ln_accumulate(smem + (it % STAGES) * STAGE);
-                if (it + STAGES - 1 < nkt) issue_tile(kt_begin + it + STAGES - 1, (it + STAGES - 1) % STAGES);
+                if (it % KSUB == 0) {
+                    // the slabs of this group (it .. it+KSUB-1) of THIS wave have landed once only younger ones are outstanding ...
+                    wait_younger<LOADS, (STAGES - 2) * KSUB>(max(0, nkt - it - KSUB));
+                    __builtin_amdgcn_s_barrier(); // ... and everybody's; the previous group is no longer read
+                }
+                if (p.ln || WQ) ln_accumulate(smem + (it % NSLOT) * STAGE);
+                if (it + AHEAD < nkt) issue_tile(kt_begin + it + AHEAD, (it + AHEAD) % NSLOT);
             }
             wait_vmcnt<0>();
             __syncthreads();
@@ -688,7 +695,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
         for (int i = 0; i < A_LD; ++i) rs1[i] = rs2[i] = 0.f;
         // prologue: STAGES-1 slabs in flight
 #pragma unroll
-        for (int s = 0; s < STAGES - 1; ++s)
+        for (int s = 0; s < AHEAD; ++s)
             if (s < nkt) issue_tile(kt_begin + s, s);
     }
     STAMP(1);
@@ -701,12 +708,14 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
 
     for (int it = 0; it < nkt; ++it) {
         // slab `it` has landed once at most the younger in-flight slabs remain outstanding
-        if constexpr (!SPEC) wait_younger<LOADS, STAGES - 2>(nkt - 1 - it);
-        __builtin_amdgcn_s_barrier(); // everyone's slab `it` is in LDS; everyone is done reading slab it-1
+        if (it % KSUB == 0) {
+            if constexpr (!SPEC) wait_younger<LOADS, (STAGES - 2) * KSUB>(max(0, nkt - it - KSUB));
+            __builtin_amdgcn_s_barrier(); // everyone's slab group is in LDS; everyone is done reading the previous group
+        }
 
         // fragment reads for the whole slab first, then the DMA issue for slab it+STAGES-1 (its address arithmetic and
         // VMEM issue run under the LDS latency), then one uninterrupted MFMA cluster
-        const f16* sA = smem + (it % STAGES) * STAGE;
+        const f16* sA = smem + (it % NSLOT) * STAGE;
         const f16* sB = sA + BM * 64;
         // Big consumer tiles (>= 32 accumulator quads: 128 registers) cannot also hold the fragments of both K halves of the
         // slab: they read and multiply one half at a time (below); everyone else reads the whole slab first.
@@ -738,7 +747,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
             if (p.ln || WQ) ln_accumulate(sA);
         }
         if constexpr (!SPEC) {
-            if (it + STAGES - 1 < nkt && !(dbg & 2)) issue_tile(kt_begin + it + STAGES - 1, (it + STAGES - 1) % STAGES);
+            if (it + AHEAD < nkt && !(dbg & 2)) issue_tile(kt_begin + it + AHEAD, (it + AHEAD) % NSLOT);
         }
         if (HALF_AT_A_TIME) {
             {
@@ -1046,8 +1055,10 @@ const TileCfg kTiles[] = {{0, 0},     {128, 128}, {128, 64}, {64, 64},   {256, 1
                           {128, 128}, {128, 128}, {256, 128}, {256, 256}, {64, 64},  {128, 64}, {64, 128}, {128, 256},
                           {64, 160},  {32, 160},
                           // 23..31: wave-specialised LDS-DMA kernel (4 consumer + 4 loader waves)
-                          {128, 128}, {128, 128}, {128, 256}, {256, 128}, {64, 64}, {64, 64}, {128, 64}, {64, 128}, {64, 160}};
-constexpr int kNumTiles = 31;
+                          {128, 128}, {128, 128}, {128, 256}, {256, 128}, {64, 64}, {64, 64}, {128, 64}, {64, 128}, {64, 160},
+                          // 32..36: wave-specialised, two slabs per barrier
+                          {64, 64}, {128, 64}, {64, 128}, {64, 160}, {128, 128}};
+constexpr int kNumTiles = 36;
 
 const f16* zero_line() { // one per device (the pointer is only valid on the device that allocated it)
     static std::atomic<f16*> z[64];
@@ -1064,20 +1075,21 @@ const f16* zero_line() { // one per device (the pointer is only valid on the dev
     return cur;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPEC = false, bool WQ = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPEC = false, bool WQ = false, int KSUB = 1>
 hipError_t launch_glds(const GemmP& p, dim3 grid, hipStream_t st) {
-    constexpr size_t ring = (size_t)STAGES * (BM + BN) * 64 * sizeof(f16);
+    constexpr size_t ring = (size_t)STAGES * KSUB * (BM + BN) * 64 * sizeof(f16);
+    static_assert(ring + 4 * BN * sizeof(float) <= 160 * 1024, "ring exceeds the 160 KiB of LDS");
     constexpr size_t ctile = (size_t)BM * (BN + 8) * sizeof(f16) + (size_t)BM * 2 * sizeof(float); // + LayerNorm row stats
     constexpr size_t smem = (ring > ctile ? ring : ctile) + (size_t)4 * BN * sizeof(float); // + per-column epilogue vectors
     static std::atomic<unsigned long long> attr_devs{0};
     if (sdod::first_use_on_device(attr_devs)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, STAGES, SPEC, WQ>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, STAGES, SPEC, WQ, KSUB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
     }
     const f16* z = zero_line();
     if (!z) return hipErrorOutOfMemory;
-    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, STAGES, SPEC, WQ>), grid, dim3(64 * WM * WN * (SPEC ? 2 : 1)), smem, st, p, z);
+    SDOD_LAUNCH((gemm_glds_kernel<BM, BN, WM, WN, STAGES, SPEC, WQ, KSUB>), grid, dim3(64 * WM * WN * (SPEC ? 2 : 1)), smem, st, p, z);
     return hipGetLastError();
 }
 
@@ -1090,7 +1102,7 @@ hipError_t launch_cfg(const GemmP& p, dim3 grid, hipStream_t st) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), grid, dim3(256), smem, st, p);
+    SDOD_LAUNCH((gemm_kernel<BM, BN, WM, WN>), grid, dim3(256), smem, st, p);
     return hipGetLastError();
 }
 
@@ -1107,7 +1119,7 @@ Plan make_plan(const sdod_gemm_desc* d) {
     int tile = d->tile;
     const bool fused = d->geglu || d->k_tail || d->ln || d->wq;
     if (fused && (tile < 6 || tile > kNumTiles)) tile = 14; // fusions live in the LDS-DMA kernel family only
-    if (d->geglu && (tile == 21 || tile == 22 || tile == 31)) tile = 14;
+    if (d->geglu && (tile == 21 || tile == 22 || tile == 31 || tile == 35)) tile = 14;
     if (d->wq && !(tile == 8 || tile == 13 || tile == 23 || tile == 24 || (tile >= 27 && tile <= 31))) tile = 23; // uint8-weight variants
     if (d->wq && d->geglu && tile == 31) tile = 23;  // value/gate pairing needs an even number of 16-column blocks per wave
     if (tile <= 0 || tile > kNumTiles) {
@@ -1185,6 +1197,25 @@ extern "C" __attribute__((visibility("default"))) int sdod_gemm_stamps(unsigned 
 #endif
 
 extern "C" int sdod_gemm_num_tiles(void) { return kNumTiles; }
+
+// template arguments of tile `tile` as the launch switch in sdod_gemm_f16 instantiates it: {BM, BN, WM, WN, STAGES (0 = the
+// register-staged gemm_kernel), SPEC, KSUB}; tools and bench.py build the kernel symbol a profiler prints from these
+extern "C" int sdod_gemm_tile_info(int tile, int out[7]) {
+    static const int kInfo[][7] = {
+        {0, 0, 0, 0, 0, 0, 0},
+        {128, 128, 2, 2, 0, 0, 1}, {128, 64, 2, 2, 0, 0, 1}, {64, 64, 2, 2, 0, 0, 1}, {256, 16, 4, 1, 0, 0, 1}, {64, 128, 2, 2, 0, 0, 1},
+        {128, 128, 2, 2, 3, 0, 1}, {128, 64, 2, 2, 4, 0, 1}, {64, 64, 2, 2, 4, 0, 1}, {128, 128, 2, 4, 3, 0, 1}, {256, 128, 4, 2, 2, 0, 1},
+        {128, 64, 4, 2, 4, 0, 1}, {256, 64, 4, 2, 3, 0, 1}, {128, 128, 2, 4, 4, 0, 1}, {128, 128, 2, 4, 2, 0, 1}, {256, 128, 4, 2, 3, 0, 1},
+        {256, 256, 2, 4, 2, 0, 1}, {64, 64, 2, 2, 8, 0, 1}, {128, 64, 2, 2, 6, 0, 1}, {64, 128, 2, 2, 6, 0, 1}, {128, 256, 2, 4, 3, 0, 1},
+        {64, 160, 2, 2, 4, 0, 1}, {32, 160, 2, 2, 6, 0, 1},
+        {128, 128, 2, 2, 4, 1, 1}, {128, 128, 2, 2, 3, 1, 1}, {128, 256, 2, 2, 3, 1, 1}, {256, 128, 2, 2, 3, 1, 1}, {64, 64, 2, 2, 8, 1, 1},
+        {64, 64, 2, 2, 4, 1, 1}, {128, 64, 2, 2, 6, 1, 1}, {64, 128, 2, 2, 6, 1, 1}, {64, 160, 2, 2, 4, 1, 1},
+        {64, 64, 2, 2, 4, 1, 2}, {128, 64, 2, 2, 3, 1, 2}, {64, 128, 2, 2, 3, 1, 2}, {64, 160, 2, 2, 2, 1, 2}, {128, 128, 2, 2, 2, 1, 2}};
+    static_assert(sizeof(kInfo) / sizeof(kInfo[0]) == kNumTiles + 1, "one row per tile");
+    if (tile < 1 || tile > kNumTiles || !out) return sdod::INVALID_ARGUMENT;
+    for (int i = 0; i < 7; ++i) out[i] = kInfo[tile][i];
+    return 0;
+}
 
 extern "C" int sdod_gemm_tile_shape(int tile, int* bm, int* bn, int* lds_dma) {
     if (tile < 1 || tile > kNumTiles) return sdod::INVALID_ARGUMENT;
@@ -1273,8 +1304,8 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         p.sa0 = d->lda; p.sa1 = 0;
     }
     const Plan pl = make_plan(d);
-    SDOD_REQUIRE(!(d->geglu && (pl.tile == 21 || pl.tile == 22 || pl.tile == 31)), "geglu needs a tile with an even number of 16-column blocks per wave");
-    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln || d->wq) || pl.tile >= 6, "geglu / tail segment / bias2 / ln / uint8 weights need an LDS-DMA tile (6..31)");
+    SDOD_REQUIRE(!(d->geglu && (pl.tile == 21 || pl.tile == 22 || pl.tile == 31 || pl.tile == 35)), "geglu needs a tile with an even number of 16-column blocks per wave");
+    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln || d->wq) || pl.tile >= 6, "geglu / tail segment / bias2 / ln / uint8 weights need an LDS-DMA tile (6..36)");
     p.splits = pl.splits;
     p.kt_per_split = pl.kt_per_split;
     if (pl.splits > 1) {
@@ -1337,14 +1368,19 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     case 28: e = launch_glds<64, 64, 2, 2, 4, true>(p, grid, st); break;
     case 29: e = launch_glds<128, 64, 2, 2, 6, true>(p, grid, st); break;
     case 30: e = launch_glds<64, 128, 2, 2, 6, true>(p, grid, st); break;
-    default: e = launch_glds<64, 160, 2, 2, 4, true>(p, grid, st); break;
+    case 31: e = launch_glds<64, 160, 2, 2, 4, true>(p, grid, st); break;
+    case 32: e = launch_glds<64, 64, 2, 2, 4, true, false, 2>(p, grid, st); break;
+    case 33: e = launch_glds<128, 64, 2, 2, 3, true, false, 2>(p, grid, st); break;
+    case 34: e = launch_glds<64, 128, 2, 2, 3, true, false, 2>(p, grid, st); break;
+    case 35: e = launch_glds<64, 160, 2, 2, 2, true, false, 2>(p, grid, st); break;
+    default: e = launch_glds<128, 128, 2, 2, 2, true, false, 2>(p, grid, st); break;
     }
     SDOD_HIP_CHECK(e);
     if (pl.splits > 1 && d->phase != 1) {
         const size_t total = (size_t)d->M * ((d->N + 3) / 4);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+        SDOD_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
         SDOD_HIP_CHECK(hipGetLastError());
     }
     return 0;
@@ -1405,7 +1441,7 @@ void touch(const void* ptr, size_t bytes, float* sink, hipStream_t st) {
     if (!ptr || bytes < 16) return;
     const size_t n = bytes / 16;
     int blocks = (int)std::min<size_t>((n + 255) / 256, 1024);
-    hipLaunchKernelGGL(touch_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)ptr, n, sink);
+    SDOD_LAUNCH(touch_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)ptr, n, sink);
 }
 } // namespace
 
@@ -1422,7 +1458,7 @@ extern "C" int sdod_gemm_time_cold(const sdod_gemm_desc* d, void* stream, int it
     float* sink = (float*)scratch;
     const size_t a_bytes = d->a_mode == SDOD_A_ROWS ? (size_t)d->M * d->lda * 2 : (size_t)d->n_img * d->h_in * d->w_in * d->c0 * 2;
     for (int i = 0; i < iters; ++i) {
-        hipLaunchKernelGGL(cache_sweep_kernel, dim3(2048), dim3(256), 0, st, (float4*)scratch, scratch_bytes / 16);
+        SDOD_LAUNCH(cache_sweep_kernel, dim3(2048), dim3(256), 0, st, (float4*)scratch, scratch_bytes / 16);
         touch(d->a, a_bytes, sink, st);
         if (d->a2 && d->c1) touch(d->a2, (size_t)d->n_img * d->h_in * d->w_in * d->c1 * 2, sink, st);
         if (d->residual) touch(d->residual, (size_t)d->M * d->ldr * 2, sink, st);

@@ -2,6 +2,7 @@
 // (same convention as the reference's libsdod.cpp:102-108: exception -> status code + message).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <atomic>
 #include <stdexcept>
@@ -26,6 +27,18 @@ struct Error : std::runtime_error {
 void set_last_error(const std::string& msg);
 const char* get_last_error();
 
+// Per-kernel device timing without a profiler: while a LaunchTimer is installed on the calling thread (Graph::profile does
+// it around every launch-list entry) the kernels are launched through hipExtLaunchKernelGGL with a start / stop event pair,
+// which the command processor stamps at the kernel's own begin and end -- the duration rocprofv3 reports for the dispatch,
+// without the queue / dispatch latency that an event pair AROUND an eager launch includes (2-4 us per launch).
+struct LaunchTimer {
+    hipEvent_t* start;
+    hipEvent_t* stop;
+    int cap;
+    int used;
+};
+extern thread_local LaunchTimer* g_launch_timer;
+
 // Kernel attributes (dynamic LDS size) are per device: true the first time the calling thread's CURRENT device meets the
 // call site owning `mask` (one bit per device ordinal; two threads racing both set the attribute, which is idempotent).
 inline bool first_use_on_device(std::atomic<unsigned long long>& mask) {
@@ -36,6 +49,18 @@ inline bool first_use_on_device(std::atomic<unsigned long long>& mask) {
 }
 
 } // namespace sdod
+
+#define SDOD_LAUNCH(kernel, grid, block, smem, stream, ...)                                                          \
+    do {                                                                                                            \
+        sdod::LaunchTimer* lt_ = sdod::g_launch_timer;                                                              \
+        if (lt_ != nullptr && lt_->used < lt_->cap) {                                                               \
+            hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(smem), stream, lt_->start[lt_->used],        \
+                                  lt_->stop[lt_->used], 0, __VA_ARGS__);                                            \
+            ++lt_->used;                                                                                            \
+        } else {                                                                                                    \
+            hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                                     \
+        }                                                                                                           \
+    } while (0)
 
 #define SDOD_STR2(x) #x
 #define SDOD_STR(x) SDOD_STR2(x)

@@ -6,6 +6,7 @@
 
 namespace sdod {
 static thread_local std::string g_last_error;
+thread_local LaunchTimer* g_launch_timer = nullptr;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 const char* get_last_error() { return g_last_error.c_str(); }
 } // namespace sdod

@@ -602,11 +602,11 @@ template <int V, int NT, int KMAX>
 static void gn_group_launch2(const GnG& g, int G, int N, bool red, hipStream_t st) {
     if constexpr (KMAX * V <= 32) {
         if (red) {
-            hipLaunchKernelGGL((gn_group_kernel<V, NT, KMAX, true>), dim3(G, N), dim3(NT), 0, st, g);
+            SDOD_LAUNCH((gn_group_kernel<V, NT, KMAX, true>), dim3(G, N), dim3(NT), 0, st, g);
             return;
         }
     }
-    hipLaunchKernelGGL((gn_group_kernel<V, NT, KMAX, false>), dim3(G, N), dim3(NT), 0, st, g);
+    SDOD_LAUNCH((gn_group_kernel<V, NT, KMAX, false>), dim3(G, N), dim3(NT), 0, st, g);
 }
 template <int V>
 static void gn_group_launch1(const GnG& g, const GroupPlan& pl, int G, int N, bool red, hipStream_t st) {
@@ -654,7 +654,7 @@ void gn_small_launch(GnP& p, int sw, size_t smem, hipStream_t st) {
         SDOD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<T, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            96 * 1024 + 4096));
     }
-    hipLaunchKernelGGL((gn_small_kernel<T, NT>), dim3(p.C / sw, p.N), dim3(NT), smem, st, p, sw);
+    SDOD_LAUNCH((gn_small_kernel<T, NT>), dim3(p.C / sw, p.N), dim3(NT), smem, st, p, sw);
     SDOD_HIP_CHECK(hipGetLastError());
 }
 
@@ -684,12 +684,12 @@ void gn_launch(GnP& p, hipStream_t st) {
     const size_t smem_stats = (size_t)p.pp * p.C * 2 * sizeof(float);
     dim3 sgrid(p.nchunks, p.N), sblock(p.cpp, p.pp);
     if (p.npass == 1)
-        hipLaunchKernelGGL((gn_stats_kernel<T, 1>), sgrid, sblock, smem_stats, st, p);
+        SDOD_LAUNCH((gn_stats_kernel<T, 1>), sgrid, sblock, smem_stats, st, p);
     else
-        hipLaunchKernelGGL((gn_stats_kernel<T, 2>), sgrid, sblock, smem_stats, st, p);
+        SDOD_LAUNCH((gn_stats_kernel<T, 2>), sgrid, sblock, smem_stats, st, p);
     SDOD_HIP_CHECK(hipGetLastError());
     if (p.nchunks > GN_INLINE_CHUNKS) {
-        hipLaunchKernelGGL(gn_collapse_kernel, dim3((p.G + 3) / 4, p.N), dim3(256), 0, st, p.partial, p.stats, p.nchunks, p.G);
+        SDOD_LAUNCH(gn_collapse_kernel, dim3((p.G + 3) / 4, p.N), dim3(256), 0, st, p.partial, p.stats, p.nchunks, p.G);
         SDOD_HIP_CHECK(hipGetLastError());
         p.partial = p.stats; // [N][1][G][2]
         p.nchunks = 1;
@@ -698,7 +698,7 @@ void gn_launch(GnP& p, hipStream_t st) {
     int bx = (int)((total + 255) / 256);
     const int cap = 1024 / (p.N > 0 ? p.N : 1) + 1;
     if (bx > cap) bx = cap;
-    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(bx, p.N), dim3(256), ((size_t)p.C * 2 + (size_t)p.G * 2) * sizeof(float), st, p);
+    SDOD_LAUNCH((gn_apply_kernel<T>), dim3(bx, p.N), dim3(256), ((size_t)p.C * 2 + (size_t)p.G * 2) * sizeof(float), st, p);
     SDOD_HIP_CHECK(hipGetLastError());
 }
 
@@ -794,7 +794,7 @@ extern "C" int sdod_ln_fold_f16(void* w, int n, int k, int ldw, const float* gam
                                 float* s_out, float* t_out, void* stream) {
     SDOD_TRY
     SDOD_REQUIRE(w && gamma && beta && s_out && t_out && n > 0 && k > 0 && ldw >= k, "bad argument");
-    hipLaunchKernelGGL(ln_fold_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (f16*)w, n, k, ldw, gamma, beta, bias_in, s_out, t_out);
+    SDOD_LAUNCH(ln_fold_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (f16*)w, n, k, ldw, gamma, beta, bias_in, s_out, t_out);
     SDOD_HIP_CHECK(hipGetLastError());
     return 0;
     SDOD_CATCH
@@ -884,7 +884,7 @@ extern "C" int sdod_layer_norm_f16(const void* x, void* y, const float* weight, 
     SDOD_TRY
     SDOD_REQUIRE(x && y, "null pointer");
     SDOD_REQUIRE(m > 0 && c > 0 && c % 8 == 0 && c <= 2048, "LayerNorm needs C % 8 == 0 and C <= 2048");
-    hipLaunchKernelGGL(layer_norm_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y,
+    SDOD_LAUNCH(layer_norm_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y,
                        weight, bias, m, c, eps);
     SDOD_HIP_CHECK(hipGetLastError());
     return 0;

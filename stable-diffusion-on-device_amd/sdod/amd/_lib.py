@@ -67,6 +67,7 @@ def _declare(lib):
         'sdod_gemm_time': (c_int, [ctypes.POINTER(GemmDesc), P, c_int, ctypes.POINTER(c_float)]),
         'sdod_gemm_time_cold': (c_int, [ctypes.POINTER(GemmDesc), P, c_int, P, c_size_t, ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),
         'sdod_gemm_num_tiles': (c_int, []),
+        'sdod_gemm_tile_info': (c_int, [c_int, ctypes.POINTER(c_int)]),
         'sdod_gemm_tile_shape': (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
         'sdod_gemm_reduce_info': (c_int, [ctypes.POINTER(GemmDesc), P]),
         'sdod_group_norm_reduce_ok': (c_int, [c_int, c_int, c_int, c_int]),
@@ -105,7 +106,7 @@ def _declare(lib):
 
 
 HIP_SYMBOLS = [
-    'sdod_gemm_f16', 'sdod_gemm_workspace_bytes', 'sdod_gemm_plan', 'sdod_gemm_num_tiles', 'sdod_gemm_tile_shape', 'sdod_gemm_time', 'sdod_gemm_time_cold', 'sdod_group_norm_workspace_bytes', 'sdod_group_norm_launches', 'sdod_group_norm_nhwc', 'sdod_gemm_reduce_info', 'sdod_group_norm_reduce_ok', 'sdod_group_norm_reduce_nhwc',
+    'sdod_gemm_f16', 'sdod_gemm_workspace_bytes', 'sdod_gemm_plan', 'sdod_gemm_num_tiles', 'sdod_gemm_tile_shape', 'sdod_gemm_tile_info', 'sdod_gemm_time', 'sdod_gemm_time_cold', 'sdod_group_norm_workspace_bytes', 'sdod_group_norm_launches', 'sdod_group_norm_nhwc', 'sdod_gemm_reduce_info', 'sdod_group_norm_reduce_ok', 'sdod_group_norm_reduce_nhwc',
     'sdod_layer_norm_f16', 'sdod_ln_fold_f16', 'sdod_attention_f16', 'sdod_softmax_rows_f16', 'sdod_geglu_f16', 'sdod_act_f16',
     'sdod_add_f16', 'sdod_concat_channels_f16', 'sdod_im2col3x3_small_f16', 'sdod_nchw_f32_to_nhwc_f16',
     'sdod_nhwc_f16_to_nchw_f32', 'sdod_latent_prep_f16', 'sdod_embedding_f16', 'sdod_timestep_features_f16', 'sdod_cfg_combine', 'sdod_stage_unet_inputs', 'sdod_randn_f32',
