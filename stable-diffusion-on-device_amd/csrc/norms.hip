@@ -20,6 +20,7 @@
 #include "host_util.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -635,6 +636,192 @@ static bool gn_group_try(const GnP& p, const GnRed* red, hipStream_t st) {
     return true;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Lean two-launch GroupNorm for fp16 maps the (image, group) kernel does not take (or takes slowly: at Cg = 10 a group is
+// 20 of every 640 bytes, so that kernel fetches 6x the bytes it uses): both passes read whole pixel rows (16-byte lanes,
+// every CU busy), thread t owns chunk t % cp of the row (its 8 channels, their <= 2 groups and their affine parameters
+// are fixed), all loads of a pass are issued before the first use, and both reductions run in a fixed order
+// (bit-reproducible).  Statistics: shifted sums per (image, pixel chunk, group) -> workspace; apply: every workgroup
+// re-reduces the short partial list (8 lanes per group + shuffles), builds scale / shift in LDS and streams its pixels.
+struct Gn2P {
+    const f16* x0;
+    const f16* x1;
+    f16* y;
+    const float* w;
+    const float* b;
+    float* partial; // [N][nchunks][G][2]
+    float* shift;   // [N][G]
+    int HW, C0, C1, C, G, Cg, cp, rp; // cp = 16-byte chunks per pixel row, rp = pixel rows per pass (256 / cp)
+    int nchunks, ppc;                 // statistics pass: pixel chunks per image, pixels per chunk
+    int ppb;                          // apply pass: pixels per workgroup
+    float eps;
+    int silu;
+};
+
+SDOD_DEVICE const f16* gn2_src(const Gn2P& p, size_t row, int c) {
+    return c < p.C0 ? p.x0 + row * p.C0 + c : p.x1 + row * p.C1 + (c - p.C0);
+}
+
+__global__ __launch_bounds__(256) void gn2_stats_kernel(const Gn2P p) {
+    __shared__ float red[256 * 4];
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const bool active = tid < p.rp * p.cp;
+    const int r0 = tid / p.cp, j = tid - r0 * p.cp;
+    const int c0 = j * 8;
+    const int gA = c0 / p.Cg;
+    const int eb = min(8, (gA + 1) * p.Cg - c0); // channels [0, eb) of the chunk belong to group gA, the rest to gA + 1
+    const size_t row0 = (size_t)n * p.HW;
+    const float shA = (float)*gn2_src(p, row0, gA * p.Cg);
+    const float shB = eb < 8 ? (float)*gn2_src(p, row0, (gA + 1) * p.Cg) : 0.f;
+    const int pix_end = min(p.HW, (chunk + 1) * p.ppc);
+    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+    for (int pix0 = chunk * p.ppc + r0; pix0 < pix_end; pix0 += 8 * p.rp) { // one trip for the UNet's maps (ppc <= 8 rp)
+        f16x8 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int pix = pix0 + k * p.rp;
+            v[k] = (active && pix < pix_end) ? ldg8(gn2_src(p, row0 + pix, c0)) : zero8();
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool ok = active && (pix0 + k * p.rp) < pix_end;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool inA = e < eb;
+                const float d = ok ? (float)v[k][e] - (inA ? shA : shB) : 0.f;
+                a1 += inA ? d : 0.f; a2 += inA ? d * d : 0.f;
+                b1 += inA ? 0.f : d; b2 += inA ? 0.f : d * d;
+            }
+        }
+    }
+    red[tid * 4 + 0] = a1; red[tid * 4 + 1] = a2; red[tid * 4 + 2] = b1; red[tid * 4 + 3] = b2;
+    __syncthreads();
+    if (tid < p.G) {
+        const int g = tid;
+        const int j0 = (g * p.Cg) >> 3, j1 = ((g + 1) * p.Cg - 1) >> 3;
+        float s1 = 0.f, s2 = 0.f;
+        for (int jj = j0; jj <= j1; ++jj) {
+            const int first = (jj * 8) / p.Cg;      // group of the chunk's first channel
+            const int slot = first == g ? 0 : 2;    // else g is the chunk's second group
+            for (int r = 0; r < p.rp; ++r) {
+                s1 += red[(r * p.cp + jj) * 4 + slot];
+                s2 += red[(r * p.cp + jj) * 4 + slot + 1];
+            }
+        }
+        float* dst = p.partial + (((size_t)n * p.nchunks + chunk) * p.G + g) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
+        if (chunk == 0) p.shift[(size_t)n * p.G + g] = (float)*gn2_src(p, row0, g * p.Cg);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn2_apply_kernel(const Gn2P p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sc = reinterpret_cast<float*>(smem_raw); // [C] scale, [C] shift, [G] mean, [G] rstd
+    float* sh = sc + p.C;
+    float* gm = sh + p.C;
+    float* gr = gm + p.G;
+    const int n = blockIdx.y, tid = threadIdx.x;
+    // (1) mean / rstd of every group from the per-chunk partials: 8 lanes per group, fixed order
+    for (int g = tid >> 3; g < p.G; g += 32) {
+        const int l = tid & 7;
+        float a = 0.f, b = 0.f;
+        for (int ch = l; ch < p.nchunks; ch += 8) {
+            const float* src = p.partial + (((size_t)n * p.nchunks + ch) * p.G + g) * 2;
+            a += src[0];
+            b += src[1];
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            a += __shfl_xor(a, o);
+            b += __shfl_xor(b, o);
+        }
+        if (l == 0) {
+            const float cnt = (float)p.HW * (float)p.Cg;
+            const float md = a / cnt;
+            float var = b / cnt - md * md;
+            var = var < 0.f ? 0.f : var;
+            gm[g] = p.shift[(size_t)n * p.G + g] + md;
+            gr[g] = 1.0f / sqrtf(var + p.eps);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 256) {
+        const int g = c / p.Cg;
+        const float wv = p.w ? p.w[c] : 1.0f, bv = p.b ? p.b[c] : 0.0f;
+        sc[c] = gr[g] * wv;
+        sh[c] = bv - gm[g] * gr[g] * wv;
+    }
+    __syncthreads();
+    // (2) stream this workgroup's pixels
+    const bool active = tid < p.rp * p.cp;
+    const int r0 = tid / p.cp, j = tid - r0 * p.cp;
+    const int c0 = j * 8;
+    float s8[8], t8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        s8[e] = active ? sc[c0 + e] : 0.f;
+        t8[e] = active ? sh[c0 + e] : 0.f;
+    }
+    const size_t row0 = (size_t)n * p.HW;
+    const int pix_begin = blockIdx.x * p.ppb, pix_end = min(p.HW, pix_begin + p.ppb);
+    for (int base = pix_begin + r0; base < pix_end; base += 4 * p.rp) {
+        f16x8 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pix = base + k * p.rp;
+            v[k] = (active && pix < pix_end) ? ldg8(gn2_src(p, row0 + pix, c0)) : zero8();
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pix = base + k * p.rp;
+            if (active && pix < pix_end) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = (float)v[k][e] * s8[e] + t8[e];
+                    if (p.silu) f = silu_f(f);
+                    o[e] = (f16)f;
+                }
+                stg8(p.y + (row0 + pix) * p.C + c0, o);
+            }
+        }
+    }
+}
+
+// true when the lean pair takes the shape (fp16, <= 256 chunks per pixel row, a chunk touches <= 2 groups, G <= 32 x ...)
+static bool gn2_fits(int c0, int c1, int groups) {
+    const int c = c0 + c1;
+    if (c % 8 || c0 % 8 || c1 % 8 || c / 8 > 256 || c > 2048 || groups > 256) return false;
+    const int cg = c / groups;
+    return cg >= 4 && (cg >= 8 || 8 % cg == 0);
+}
+
+static void gn2_launch(const GnP& q, hipStream_t st) {
+    Gn2P p{};
+    p.x0 = (const f16*)q.x0; p.x1 = (const f16*)q.x1; p.y = (f16*)q.y; p.w = q.w; p.b = q.b;
+    p.partial = q.partial; p.shift = q.shift;
+    p.HW = q.HW; p.C0 = q.C0; p.C1 = q.C1; p.C = q.C; p.G = q.G; p.Cg = q.Cg; p.eps = q.eps; p.silu = q.silu;
+    p.cp = q.C / 8;
+    p.rp = 256 / p.cp;
+    // statistics: <= 8 rows of the pass pattern per workgroup, and enough workgroups to cover the chip (~512), capped by the
+    // workspace layout (GN_MAX_CHUNKS chunks per image)
+    int ppc = p.rp * 8;
+    while (ppc > p.rp && (size_t)((q.HW + ppc / 2 - 1) / (ppc / 2)) * q.N <= 512) ppc /= 2;
+    p.nchunks = (q.HW + ppc - 1) / ppc;
+    while (p.nchunks > 1024) { ppc *= 2; p.nchunks = (q.HW + ppc - 1) / ppc; }
+    p.ppc = ppc;
+    SDOD_LAUNCH(gn2_stats_kernel, dim3(p.nchunks, q.N), dim3(256), 0, st, p);
+    SDOD_HIP_CHECK(hipGetLastError());
+    int ppb = p.rp * 8;
+    while (ppb > p.rp && (size_t)((q.HW + ppb / 2 - 1) / (ppb / 2)) * q.N <= 1024) ppb /= 2;
+    p.ppb = ppb;
+    const int bx = (q.HW + ppb - 1) / ppb;
+    SDOD_LAUNCH(gn2_apply_kernel, dim3(bx, q.N), dim3(256), ((size_t)q.C * 2 + (size_t)q.G * 2) * sizeof(float), st, p);
+    SDOD_HIP_CHECK(hipGetLastError());
+}
+
 static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 
 // single-launch path eligibility (also what sdod_group_norm_launches reports).  Up to 256 pixels a 256-thread workgroup
@@ -670,8 +857,28 @@ bool gn_try_small(GnP& p, hipStream_t st) {
 
 constexpr int GN_INLINE_CHUNKS = 128; // up to here the apply pass reduces the partials itself (two launches per GroupNorm)
 
+// which fp16 path: the (image, group) kernel, or the lean statistics + apply pair (SDOD_GN_PATH=two: developer switch for
+// tools/gn_bench.py and the kernel tests)
+static int gn_path_override() {
+    static const int v = [] {
+        const char* e = std::getenv("SDOD_GN_PATH");
+        return !e ? 0 : e[0] == 'g' ? 1 : e[0] == 't' ? 2 : 0;
+    }();
+    return v;
+}
+static bool gn_prefer_pair(const GnP& p) {
+    if (gn_path_override() == 1) return false;
+    // Measured on MI355X (profiles/r02_gn_bench.txt): the pair is no faster than the group kernel where it was meant to win
+    // (64x64 x 320 channels: 18.9 vs 18.4 us) and 2-3x slower on small maps, so it is never chosen by default.
+    return gn_path_override() == 2;
+}
+
 template <typename T>
 void gn_launch(GnP& p, hipStream_t st) {
+    if (sizeof(T) == 2 && p.G <= 32 && gn2_fits(p.C0, p.C1, p.G) && gn_prefer_pair(p)) {
+        gn2_launch(p, st);
+        return;
+    }
     if (sizeof(T) == 2 && gn_group_try(p, nullptr, st)) return;
     if (gn_try_small<T>(p, st)) return;
     const int cp = p.C / 8;
@@ -802,7 +1009,8 @@ extern "C" int sdod_ln_fold_f16(void* w, int n, int k, int ldw, const float* gam
 
 extern "C" int sdod_group_norm_launches(int hw, int c, int groups, int dtype) {
     if (hw <= 0 || c <= 0 || groups <= 0 || c % groups) return 0;
-    if (dtype == SDOD_F16 && c % 8 == 0 && gn_group_plan(hw, c, 0, c / groups, false).v) return 1;
+    if (dtype == SDOD_F16 && groups <= 32 && gn2_fits(c, 0, groups) && gn_path_override() == 2) return 2;
+    if (dtype == SDOD_F16 && c % 8 == 0 && gn_group_plan(hw, c, 0, c / groups, false).v && gn_path_override() != 2) return 1;
     return gn_small_fits(hw, c, c / groups, dtype == SDOD_F16 ? 2 : 4) ? 1 : 2; // (+1 collapse launch on very large maps)
 }
 

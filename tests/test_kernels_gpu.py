@@ -340,7 +340,8 @@ def test_group_norm_with_fused_splitk_reduce(n, hw_side, cin, cout, c1, split, w
     y = ops.group_norm_reduce(desc, n, hw, 32, gw, gb, 1e-5, True, x2=x2)
     torch.cuda.synchronize()
     assert torch.equal(out, full), 'x written by the fused kernel differs from splitk_reduce'
-    assert torch.equal(y, y_ref), 'GroupNorm output differs from the two-launch path'
+    if os.environ.get('SDOD_GN_PATH') != 'two':      # (forced pair path: different reduction order, checked by tolerance below)
+        assert torch.equal(y, y_ref), 'GroupNorm output differs from reduce + GroupNorm'
     ref = F.silu(F.group_norm(torch.cat([full.reshape(n, hw, cout).float().cpu()] + ([x2.float().cpu()] if c1 else []), -1).permute(0, 2, 1),
                               32, gw.cpu(), gb.cpu(), 1e-5).permute(0, 2, 1))
     check(y, ref, name='gn fused reduce')
