@@ -479,7 +479,8 @@ IoSlot Graph::io(bool output, int index) const {
 // launch meets inside a replay: the UNet's weights are 1.7 GB, the Infinity Cache 256 MiB.  SDOD_AUTOTUNE=0 disables the
 // tuner (gemm.hip's static heuristic decides), SDOD_AUTOTUNE=hot ranks with back-to-back launches instead.
 namespace {
-const int kCandidates[] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36}; // (25, 26 spill in their epilogue only; the tuner decides)
+const int kCandidates[] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, // (25, 26 spill in their epilogue only; the tuner decides)
+                           37, 38, 39, 40, 41, 42, 43, 44, 45}; // halo-patch convolution tiles: rejected by every other descriptor
 
 struct ShapeKey {
     int v[12];

@@ -25,7 +25,9 @@
 #include "sdod_hip.h"
 #include "host_util.h"
 
+#include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -65,6 +67,16 @@ struct GemmP {
     int wq;
     const float* w_scale;
     const float* w_off;
+    // halo-patch convolution (conv_halo_kernel, tiles 37..): geometry of one workgroup's output tile and of the input patch
+    // it keeps in LDS, all host-computed (halo_geometry)
+    int h_tw, h_th;          // tile = h_tw consecutive pixels of h_th rows per part (h_tw == BM: a row segment; else whole rows)
+    int h_pw, h_ppix;        // patch row pitch h_tw + 2, pixels of one part's patch (h_th + 2) * h_pw
+    int h_npix, h_nr;        // patch pixels over all parts (a tile taller than the image spans `parts` whole images), DMA rounds
+    int h_nimg;              // images in the batch (parts past the last one read zeros)
+    int h_patch_halves;      // LDS halves of one patch buffer
+    int h_colv_off;          // byte offset of the per-column epilogue vectors in LDS
+    int h_main_splits;       // splits that walk the 3x3 taps (split h_main_splits, when k_tail != 0, walks the 1x1 tail)
+    unsigned mg_tw, sh_tw, mg_th, sh_th, mg_pw, sh_pw, mg_pp, sh_pp;
 };
 
 constexpr int BK = 64;
@@ -347,6 +359,18 @@ SDOD_DEVICE void wait_younger(int y) {
     else if constexpr (Y > 0) wait_younger<LOADS, Y - 1>(y);
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): n >= 32 waits for everything
+SDOD_DEVICE void wait_vmcnt_dyn(int n) {
+    switch (n) {
+#define SDOD_W(k) case k: wait_vmcnt<k>(); break;
+        SDOD_W(0) SDOD_W(1) SDOD_W(2) SDOD_W(3) SDOD_W(4) SDOD_W(5) SDOD_W(6) SDOD_W(7) SDOD_W(8) SDOD_W(9) SDOD_W(10) SDOD_W(11)
+        SDOD_W(12) SDOD_W(13) SDOD_W(14) SDOD_W(15) SDOD_W(16) SDOD_W(17) SDOD_W(18) SDOD_W(19) SDOD_W(20) SDOD_W(21) SDOD_W(22)
+        SDOD_W(23) SDOD_W(24) SDOD_W(25) SDOD_W(26) SDOD_W(27) SDOD_W(28) SDOD_W(29) SDOD_W(30) SDOD_W(31)
+#undef SDOD_W
+    default: wait_vmcnt<0>(); break;
+    }
+}
+
 // developer builds only (make lib/libsdod_stamp.so): wall-clock stamps (s_memrealtime, 100 MHz) of the phases of every
 // workgroup -- 0 entry, 1 prologue issued, 2 main loop drained, 3 epilogue tile staged, 4 stores retired -- read back by
 // sdod_gemm_stamps() (tools/gemm_phases.py).  In the product build the macro is empty.
@@ -357,8 +381,17 @@ __device__ unsigned long long g_stamp[8 * 8192];
         const unsigned wg_ = blockIdx.x + gridDim.x * blockIdx.z;                                           \
         if (threadIdx.x == 0 && wg_ < 8192) g_stamp[wg_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime();     \
     } while (0)
+// ... and a shader-clock (s_memtime) timeline of ONE main-loop iteration (the 20th) of consumer wave 0 of every workgroup:
+// TL(k) at up to 16 points, read back by sdod_gemm_timeline()
+__device__ unsigned long long g_timeline[16 * 8192];
+#define TL(k)                                                                                               \
+    do {                                                                                                    \
+        const unsigned wg_ = blockIdx.x + gridDim.x * blockIdx.z;                                           \
+        if (tl_on && wg_ < 8192) g_timeline[wg_ * 16 + (k)] = __builtin_amdgcn_s_memtime();                \
+    } while (0)
 #else
 #define STAMP(i)
+#define TL(k)
 #endif
 
 // 8 affine-uint8 weight codes (two dwords) -> f16x8 of (q - 128), exactly: byte b next to 0x64 is the fp16 number 1024 + b
@@ -402,7 +435,11 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int A_LD = BM / (8 * NL), B_LD = BN / (8 * NL); // DMA instructions per loading wave per slab (8 rows each)
+#if defined(SDOD_GEMM_ABLATE) && (SDOD_GEMM_ABLATE & 8)
+    constexpr int LOADS = B_LD;                   // developer build: the A operand is never fetched (what would a free A cost?)
+#else
     constexpr int LOADS = A_LD + B_LD;
+#endif
     constexpr int STAGE = (BM + BN) * 64;         // halves per slab
     constexpr int SC = BN + 8;
     static_assert((NW == 4 || NW == 8) && BM % (8 * NL) == 0 && BN % (8 * NL) == 0 && TM >= 1 && TN >= 1, "tile shape");
@@ -533,7 +570,8 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
         const f16* src = second ? p.a1 : p.a0;
         const int sa = second ? p.sa1 : p.sa0;
         const int ccs = second ? cc - p.c0 : cc;
-        if (!p.ups) {
+        if (dbg & 8) {
+        } else if (!p.ups) {
             const int sdelta = (r * p.w_in + sx) * sa + ccs; // wave-uniform
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) {
@@ -977,6 +1015,569 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
 #endif
 }
 
+// Keep a wave-uniform value in an SGPR for good.  Kernel arguments are otherwise re-read from the kernarg segment (s_load)
+// wherever the register allocator finds that cheaper -- also inside main loops, where a pending scalar load forces every
+// following LDS wait to lgkmcnt(0) (SMEM returns out of order), i.e. kills the counted waits of a software pipeline.
+template <class T>
+SDOD_DEVICE T sgpr_pin(T v) {
+    if constexpr (sizeof(T) == 8) {
+        unsigned long long u = (unsigned long long)v;
+        asm volatile("" : "+s"(u));
+        return (T)u;
+    } else {
+        asm volatile("" : "+s"(v));
+        return v;
+    }
+}
+
+// 16-byte-per-lane LDS-DMA issued BEHIND THE COMPILER'S BACK.  The waitcnt pass models global_load_lds as a FLAT access that
+// may touch LDS: while one is pending (and it cannot see the hand-counted s_waitcnt vmcnt that retire them) it turns every
+// LDS wait of the wave into lgkmcnt(0) -- a wave that both fetches by DMA and software-pipelines its fragment reads
+// (conv_halo_kernel's consumers) would wait for the fragments it has just requested.  lds_dst must be wave-uniform.
+SDOD_DEVICE void lds_dma16_opaque(const void* g, f16* lds_dst) {
+    const unsigned a = (unsigned)(uintptr_t)(lds_void_ptr)lds_dst;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(a) : "memory", "m0");
+}
+
+// ring depth of conv_halo_kernel's tail program: its slots hold A next to B, so fewer of them fit
+constexpr int halo_tail_stages(int bm, int bn, int stages) {
+    const int fit = (150 * 1024) / ((bm + bn) * 128);
+    return fit < stages ? fit : stages;
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <int N, int I = 0, class F>
+SDOD_DEVICE void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_halo_kernel: the 3x3 stride-1 convolution with the input HALO PATCH resident in LDS (tiles 37..).
+//
+// The implicit-im2col GEMM above re-fetches every input pixel nine times (once per tap) and its main loop is paced by the
+// LDS-DMA stream: slab time = fixed part + bytes / ~75 GB/s per CU (tools/gemm_phases.py with and without the A operand,
+// profiles/r02_gemm_phases_noA.txt).  Here K is walked CHANNEL-CHUNK major, tap minor: for each 64-channel chunk the
+// workgroup holds the (rows + 2) x (width + 2) input patch of its output tile in LDS (zero halo included) and the nine
+// taps of the chunk read their A fragments from that one patch at a shifted pixel offset -- the A operand crosses the
+// L2 -> LDS path 2-4.5x less often (3 of 9 for a one-row tile, 18 of 144 for a 16x16 image), so tiles can be TALL and
+// NARROW (128x80, 256x32: few weight bytes per output) where the im2col kernel needs them square.
+//   * 4 LOADER waves stream the weight slabs (B: [BN][64] per tap and chunk) through a STAGES-deep ring exactly as in the
+//     wave-specialised GEMM (counted vmcnt, one barrier per slab); the 8-row DMA groups of a slab are dealt round-robin, so
+//     a wave may issue one group fewer than its neighbour (BN = 80: 3,3,2,2) -- the loop is instantiated per count.
+//   * 4 CONSUMER waves own the accumulators.  They also fetch the patches: two double-buffered patch images; the DMA
+//     rounds of chunk c+1 are issued two per tap while chunk c is multiplied, each wave waits for its own rounds
+//     (vmcnt(0)) before the barrier that opens chunk c+1.  A patch pixel is one 128-byte line, 16-byte pieces XOR-swizzled
+//     with the pixel index (the fragment rows of one MFMA operand are 16 consecutive pixels at any tap shift, so the reads
+//     stay conflict-free exactly like the row-major slab).
+//   * consumer pipeline: fragments of K-half h+1 are requested before the MFMAs of half h are issued, across the slab
+//     boundary too (barrier -> next slab's first reads -> this slab's last MFMAs), so the LDS latency hides under the
+//     matrix pipe instead of adding to it.
+//   * a fused 1x1 skip connection (k_tail) has no halo to share: it becomes ONE EXTRA split-K slice (blockIdx.z ==
+//     h_main_splits) whose workgroups run the plain ring program (A and B slabs by the loaders) on the tail columns; the
+//     partial slabs meet in splitk_reduce_kernel like any split.
+// Output rows of a tile are consecutive (a row segment, whole rows, or whole images), so the epilogue is the GEMM's.
+template <int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16* __restrict__ zeros) {
+    static_assert(WM * WN == 4, "four consumer waves (one per SIMD) + four loader waves");
+    constexpr int NL = 4;
+    constexpr int NT = 512;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BN % 8 == 0 && BM % 32 == 0, "tile shape");
+    constexpr int BG = BN / 8;                  // 8-row DMA groups of one weight slab
+    constexpr int B_LDX = (BG + NL - 1) / NL;   // ... per loader wave, at most
+    constexpr int A_LD = BM / (8 * NL);         // tail program: A groups per loader wave
+    constexpr int SC = BN + 8;
+    constexpr int NRMAX = BM <= 64 ? 7 : BM <= 128 ? 9 : 13; // patch DMA rounds (256 lanes x 16 bytes each) this tile can need
+    constexpr int AHEAD = STAGES - 1;
+#ifdef SDOD_GEMM_ABLATE
+    constexpr int dbg = SDOD_GEMM_ABLATE; // developer builds: 16 no patch DMA inside the loop, 32 no weight DMA inside the loop, 64 no MFMA,
+                                          // 128 no barrier inside the loop, 256 no fragment reads inside the loop
+#else
+    constexpr int dbg = 0;
+#endif
+    // the tail program's ring holds A next to B: as many of the STAGES slots as fit
+    constexpr int TST = halo_tail_stages(BM, BN, STAGES);
+    constexpr int TAHEAD = TST - 1;
+    static_assert(TST >= 2 && B_LDX * AHEAD < 64 && (B_LDX + A_LD) * TAHEAD < 64, "vmcnt is a 6-bit counter");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    f16* smem = reinterpret_cast<f16*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_consumer = wave < 4;
+    const int lw = wave & 3, cw = wave & 3;
+    const int wm = cw / WN, wn = cw % WN;
+    STAMP(0);
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int lid = xcd_remap(blockIdx.x, nwg);
+    const int tile_m = fast_div(lid, p.mg_tn, p.sh_tn);
+    const int tile_n = lid - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.z;
+    const bool tail_wg = p.k_tail != 0 && split == p.h_main_splits;
+    const int cin = p.c0 + p.c1;
+    // slabs of this workgroup: [kt_begin, kt_end) of the 9 * (cin / 64) tap slabs, or all tail slabs
+    int kt_begin, kt_end;
+    if (tail_wg) {
+        kt_begin = 0;
+        kt_end = (p.K - p.k_tail) / BK;
+    } else {
+        const int ktm = 9 * (cin / BK);
+        kt_begin = split * p.kt_per_split;
+        kt_end = min(ktm, kt_begin + p.kt_per_split);
+    }
+    const int nkt = kt_end - kt_begin;
+
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ lrow;
+    const int frag_row = lane & 15;
+    const int frag_chunk = lane >> 4;
+    const int e_m = lane & 15;
+    const int e_n = (lane >> 4) * 4;
+
+    // per-column epilogue vectors -> LDS, issued before anything else (they are older than every slab / patch)
+    float* colv = reinterpret_cast<float*>(smem_raw + p.h_colv_off); // [2][BN]: bias, bias2
+    {
+        constexpr int CHUNKS = (BN + 63) / 64;
+        const float* zf = reinterpret_cast<const float*>(zeros) + lane;
+        for (int job = wave; job < 2 * CHUNKS; job += 8) { // wave-uniform
+            const int vec = job / CHUNKS, q = job - vec * CHUNKS;
+            const int c = q * 64 + lane, n = n0 + c;
+            const float* base = vec == 0 ? p.bias : p.bias2;
+            const float* g = (base != nullptr && n < p.N) ? base + n : zf;
+            if (c < BN) __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(colv + vec * BN + q * 64), 4, 0, 0);
+        }
+    }
+
+    f16* sC = smem;
+    auto store_phase = [&]() {
+        constexpr int CPR = BN / 8; // 16-byte chunks per output tile row
+        const bool vec_ok = (p.N % 8 == 0) && (p.ldo % 8 == 0) && (p.residual == nullptr || p.ldr % 8 == 0);
+        for (int idx = tid; idx < BM * CPR; idx += NT) {
+            const int row = idx / CPR;
+            const int ch = idx - row * CPR;
+            const int m = m0 + row, n = n0 + ch * 8;
+            if (m >= p.M || n >= p.N) continue;
+            f16x8 v = *reinterpret_cast<const f16x8*>(sC + row * SC + ch * 8);
+            if (vec_ok) {
+                if (p.residual != nullptr) {
+                    const f16x8 rr = ldg8(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)rr[e]);
+                }
+                stg8(p.out + (size_t)m * p.ldo + n, v);
+            } else {
+                for (int e = 0; e < 8; ++e) {
+                    if (n + e < p.N) {
+                        float f = (float)v[e];
+                        if (p.residual != nullptr) f += (float)p.residual[(size_t)m * p.ldr + n + e];
+                        p.out[(size_t)m * p.ldo + n + e] = (f16)f;
+                    }
+                }
+            }
+        }
+    };
+
+    if (!is_consumer) {
+        // =============================== LOADER waves ===============================
+        // CNT = 8-row weight groups this wave issues per slab (groups lw, lw + 4, ...)
+        auto loader = [&](auto cnt_c) {
+            constexpr int CNT = decltype(cnt_c)::value;
+            constexpr int NB = CNT > 0 ? CNT : 1;
+            const f16* b_row[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int n = n0 + (i * NL + lw) * 8 + lrow;
+                b_row[i] = (i < CNT && n < p.N) ? p.w + (size_t)n * p.ldw + lchunk * 8 : zeros;
+            }
+            if (!tail_wg) {
+                constexpr int SLOT = BN * 64;
+                // ---- the patch pieces this lane fetches (one 16-byte piece per DMA round), as input pixel indices (-1: zero halo)
+                const int hw = p.h_out * p.w_out;
+                const int img0 = fast_div(m0, p.mg_hw, p.sh_hw);
+                const int rem0 = m0 - img0 * hw;
+                const int y0 = fast_div(rem0, p.mg_w, p.sh_w);
+                const int x0 = rem0 - y0 * p.w_out;
+                int poff[NRMAX];
+#pragma unroll
+                for (int j = 0; j < NRMAX; ++j) {
+                    const int pix = (j * 256 + lw * 64 + lane) >> 3;
+                    const int part = fast_div(pix, p.mg_pp, p.sh_pp);
+                    const int r2 = pix - part * p.h_ppix;
+                    const int py = fast_div(r2, p.mg_pw, p.sh_pw);
+                    const int px = r2 - py * p.h_pw;
+                    const int gy = y0 - 1 + py, gx = x0 - 1 + px, img = img0 + part;
+                    const bool ok = pix < p.h_npix && img < p.h_nimg && (unsigned)gy < (unsigned)p.h_in && (unsigned)gx < (unsigned)p.w_in;
+                    poff[j] = ok ? (img * p.h_in + gy) * p.w_in + gx : -1;
+                }
+                const int c0_s = sgpr_pin(p.c0), sa0_s = sgpr_pin(p.sa0), sa1_s = sgpr_pin(p.sa1), nr_s = sgpr_pin(p.h_nr);
+                const int ph_s = sgpr_pin(p.h_patch_halves), cin_s = sgpr_pin(cin);
+                const f16* a0_s = sgpr_pin(p.a0);
+                const f16* a1_s = sgpr_pin(p.a1);
+                auto issue_patch = [&](int chunk, int buf, auto j_c) { // chunk, buf wave-uniform
+                    constexpr int j = decltype(j_c)::value;
+                    const int cc = chunk * BK;
+                    const bool second = cc >= c0_s;
+                    const f16* src = second ? a1_s : a0_s;
+                    const int sa = second ? sa1_s : sa0_s;
+                    const int ccs = (second ? cc - c0_s : cc) + lchunk * 8;
+                    const f16* g = poff[j] >= 0 ? src + poff[j] * sa + ccs : zeros;
+                    f16* dst = smem + STAGES * SLOT + buf * ph_s + (j * 256 + lw * 64) * 8;
+                    __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)dst, 16, 0, 0);
+                };
+                // The patch of chunk c+1 rides on the weight slabs of chunk c: RPT rounds in front of the slab of tap t, for the
+                // taps t >= AHEAD only (slab s is issued after barrier s - AHEAD: from tap AHEAD on, every consumer has left
+                // chunk c-1, whose buffer the rounds overwrite).  Everything issued in front of slab 9(c+1) -- all of the patch
+                // -- has landed when that slab has (vmcnt retires in order), so the one counted wait per slab covers both.
+                constexpr int RPT = (NRMAX + (9 - AHEAD) - 1) / (9 - AHEAD);
+                static_assert(AHEAD < 9 && (B_LDX + RPT) * (AHEAD - 1) < 32, "patch rounds per tap / wait table");
+                auto rounds_at = [&](int t) { return t < AHEAD ? 0 : max(0, min(RPT, nr_s - RPT * (t - AHEAD))); }; // DMA rounds in front of tap t
+                const int chunk_begin = kt_begin / 9, chunk_end = kt_end / 9;
+                int k0 = chunk_begin * BK;  // weight column of the next slab to issue: tap * cin + chunk * 64
+                int s_slot = 0;             // ... and its ring slot
+                static_for<NRMAX>([&](auto j_c) {
+                    if (decltype(j_c)::value < nr_s) issue_patch(chunk_begin, 0, j_c);
+                });
+                STAMP(1);
+                // s = slab to issue, it = s - AHEAD = slab whose barrier is due; nine taps unrolled, so taps are compile-time
+                for (int c = chunk_begin; c <= chunk_end; ++c) { // (the extra pass only drains the last AHEAD barriers)
+                    const bool has_next = c + 1 < chunk_end;
+                    const int s_base = (c - chunk_begin) * 9;
+                    static_for<9>([&](auto t_c) {
+                        constexpr int t = decltype(t_c)::value;
+                        const int sidx = s_base + t, it = sidx - AHEAD;
+                        if (it >= 0 && it < nkt) {
+                            // DMA instructions younger than slab `it`: the slabs it+1 .. it+AHEAD-1 and the patch rounds in front of them
+                            constexpr int ti = (t + 9 - AHEAD) % 9;                   // tap of slab `it`
+                            int young = min(AHEAD - 1, nkt - it - 1) * CNT;
+                            // rounds ride only on taps >= AHEAD of the chunk slab `it` belongs to (a wrap lands on taps < AHEAD: none)
+                            const bool it_has_next = (t >= AHEAD ? c : c - 1) + 1 < chunk_end;
+                            if (it_has_next) {
+#pragma unroll
+                                for (int u = ti + 1; u <= ti + AHEAD - 1 && u <= 8; ++u) young += rounds_at(u);
+                            }
+                            if (dbg & 32) wait_vmcnt<0>();
+                            else wait_vmcnt_dyn(young);
+                            if (!(dbg & 128)) __builtin_amdgcn_s_barrier();
+                        }
+                        if (sidx < nkt && !((dbg & 32) && sidx >= AHEAD)) {
+                            if (t >= AHEAD && has_next && !(dbg & 16)) {
+                                static_for<RPT>([&](auto r_c) {
+                                    constexpr int j = RPT * (t - AHEAD) + decltype(r_c)::value;
+                                    if constexpr (j >= 0 && j < NRMAX) {
+                                        if (j < nr_s) issue_patch(c + 1, (c + 1 - chunk_begin) & 1, std::integral_constant<int, j>{});
+                                    }
+                                });
+                            }
+                            f16* sB = smem + s_slot * SLOT;
+#pragma unroll
+                            for (int i = 0; i < CNT; ++i) {
+                                const f16* g = b_row[i] + (b_row[i] == zeros ? 0 : k0);
+                                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * NL + lw) * 8 * 64), 16, 0, 0);
+                            }
+                            k0 += t == 8 ? BK - 8 * cin_s : cin_s;
+                            s_slot = s_slot + 1 == STAGES ? 0 : s_slot + 1;
+                        }
+                    });
+                }
+            } else {
+                // 1x1 tail: plain [BM][64] A slabs (the centre pixel of each output row) next to the weight slab
+                constexpr int SLOT = (BM + BN) * 64;
+                int a_pix[A_LD];
+#pragma unroll
+                for (int i = 0; i < A_LD; ++i) {
+                    const int m = m0 + (i * NL + lw) * 8 + lrow;
+                    a_pix[i] = m < p.M ? m : -1;
+                }
+                auto issue = [&](int j, int slot) {
+                    const int kk = j * BK;
+                    const bool sec = kk >= p.tc0;
+                    const f16* src = sec ? p.t1 : p.t0;
+                    const int sa = sec ? p.tc1 : p.tc0;
+                    const int ccs = (sec ? kk - p.tc0 : kk) + lchunk * 8;
+                    f16* sA = smem + slot * SLOT;
+                    f16* sB = sA + BM * 64;
+#pragma unroll
+                    for (int i = 0; i < A_LD; ++i) {
+                        const f16* g = a_pix[i] >= 0 ? src + a_pix[i] * sa + ccs : zeros;
+                        __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sA + (i * NL + lw) * 8 * 64), 16, 0, 0);
+                    }
+                    const int k0 = p.k_tail + kk;
+#pragma unroll
+                    for (int i = 0; i < CNT; ++i) {
+                        const f16* g = b_row[i] + (b_row[i] == zeros ? 0 : k0);
+                        __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * NL + lw) * 8 * 64), 16, 0, 0);
+                    }
+                };
+#pragma unroll
+                for (int s = 0; s < TAHEAD; ++s)
+                    if (s < nkt) issue(s, s);
+                STAMP(1);
+                for (int it = 0; it < nkt; ++it) {
+                    wait_younger<A_LD + CNT, TST - 2>(max(0, nkt - it - 1));
+                    __builtin_amdgcn_s_barrier();
+                    if (it + TAHEAD < nkt) issue(it + TAHEAD, (it + TAHEAD) % TST);
+                }
+            }
+        };
+        constexpr int REM = BG % NL; // waves lw < REM carry one group more (REM == 0: all the same)
+        if (REM == 0 || lw < REM) loader(std::integral_constant<int, B_LDX>{});
+        else loader(std::integral_constant<int, B_LDX - 1>{});
+        wait_vmcnt<0>();
+        __syncthreads();
+        STAMP(2);
+        if (p.splits > 1) return;
+        __syncthreads(); // the consumers have staged the output tile
+        STAMP(3);
+        store_phase();
+#ifdef SDOD_GEMM_STAMP
+        wait_vmcnt<0>();
+        STAMP(4);
+#endif
+        return;
+    }
+
+    // =============================== CONSUMER waves ===============================
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int b_off0 = lds_off(wn * WTN + frag_row, frag_chunk); // weight fragment (j = 0, K half 0) inside a slab
+
+    if (!tail_wg) {
+        constexpr int SLOT = BN * 64;
+        // ---- LDS byte address of this lane's A fragment (K half 0) for every tap and fragment row, in patch buffer 0:
+        // pixel (row + tap shift) * 128 + swizzled 16-byte piece.  Nine taps unrolled below, so these are plain registers;
+        // the other K half is the same address with bit 6 flipped, the other patch buffer a constant further.
+        const unsigned smem_base = (unsigned)(uintptr_t)(lds_void_ptr)smem;
+        unsigned a_addr[9][TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = wm * WTM + i * 16 + frag_row;
+            const int ly = fast_div(r, p.mg_tw, p.sh_tw);
+            const int lx = r - ly * p.h_tw;
+            const int part = fast_div(ly, p.mg_th, p.sh_th);
+            const int abase = part * p.h_ppix + (ly - part * p.h_th) * p.h_pw + lx; // patch pixel under tap (0, 0)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int pix = abase + (t / 3) * p.h_pw + t % 3;
+                a_addr[t][i] = smem_base + (unsigned)(STAGES * SLOT * 2) + (unsigned)(pix * 128 + ((frag_chunk ^ (pix & 7)) << 4));
+            }
+        }
+        unsigned pdelta = (unsigned)sgpr_pin(p.h_patch_halves) * 2u; // byte distance to the other patch buffer (sign flips per chunk)
+        const unsigned b_addr0 = smem_base + (unsigned)b_off0 * 2u;  // weight fragment j = 0, K half 0, ring slot 0
+        STAMP(1);
+
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        f16x8 fa[2][TM], fb[2][TN];
+        auto lds16 = [](unsigned addr) { return *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>((uintptr_t)addr); };
+        // fragments of (tap t, K half ks) of the slab in ring slot `slot` -> register set b
+        auto read_half = [&](auto b_c, auto t_c, auto ks_c, int slot) {
+            constexpr int b = decltype(b_c)::value, t = decltype(t_c)::value, ks = decltype(ks_c)::value;
+            if (dbg & 256) return;
+            const unsigned sb = (b_addr0 + (unsigned)slot * (SLOT * 2)) ^ (ks << 6);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[b][i] = lds16(a_addr[t][i] ^ (ks << 6));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[b][j] = lds16(sb + j * 16 * 128);
+        };
+        auto mfma_half = [&](auto b_c) {
+            constexpr int b = decltype(b_c)::value;
+            if (dbg & 64) { // keep the fragment reads alive without the matrix pipe
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[b][j]));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[b][i]));
+                return;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(fb[b][j], fa[b][i], acc[i][j]);
+        };
+
+        auto interleave_reads_with_mfmas = [] { // scheduling directive for the region since the last sched_barrier
+            constexpr int NRD = TM + TN, NMF = TM * TN, PAIRS = NRD < NMF ? NRD : NMF;
+            __builtin_amdgcn_sched_group_barrier(0x002, TM + 2, 0); // the address arithmetic of the reads first
+            static_for<PAIRS>([](auto) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // one LDS read
+            });
+            if constexpr (NMF > PAIRS) __builtin_amdgcn_sched_group_barrier(0x008, NMF - PAIRS, 0);
+            if constexpr (NRD > PAIRS) __builtin_amdgcn_sched_group_barrier(0x100, NRD - PAIRS, 0);
+        };
+
+        wait_vmcnt<0>(); // the epilogue vectors this wave requested have landed
+        // ... and once more as a BUILTIN, all counters (the waitcnt pass cannot see the asm form): when the loop starts it must
+        // know that neither a scalar load nor the epilogue vectors' LDS-DMA is pending, or every LDS wait inside the loop
+        // degrades to lgkmcnt(0) (SMEM returns out of order; a pending "flat" LDS access forces full waits) and the
+        // fragment double-buffer is lost.  (The consumers issue NO vector-memory instruction inside the loop: one issued
+        // behind the loaders' saturated queue cost ~100 ns of the wave's time, tools/gemm_phases.py --timeline.)
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_s_barrier(); // slab 0 and the first patch are in LDS (the loaders waited for them)
+        int slot = 0;
+        const int nchunk = nkt / 9;
+        read_half(I0{}, I0{}, I0{}, 0);
+        for (int c = 0; c < nchunk; ++c) {
+            const bool last_chunk = c + 1 == nchunk;
+            static_for<9>([&](auto t_c) {
+                constexpr int t = decltype(t_c)::value;
+                using TNEXT = std::integral_constant<int, (t + 1) % 9>;
+                // K half 1 of this slab is requested while K half 0 is multiplied, READS INTERLEAVED WITH THE MFMAs: a wave issues
+                // in order, an MFMA holds its issue port for 8 of its 16 cycles, so a fragment read placed between two MFMAs is
+                // free while a block of reads in front of the MFMA block leaves the matrix pipe idle for its whole issue time
+                read_half(I1{}, t_c, I1{}, slot);
+                mfma_half(I0{});
+                interleave_reads_with_mfmas();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): my reads of this slab are done, the ring slot may be refilled
+                if (!(t == 8 && last_chunk)) {
+                    if (!(dbg & 128)) __builtin_amdgcn_s_barrier();
+                    slot = slot + 1 == STAGES ? 0 : slot + 1;
+                    if constexpr (t == 8) { // next chunk: its patch sits in the other buffer
+#pragma unroll
+                        for (int tt = 0; tt < 9; ++tt)
+#pragma unroll
+                            for (int i = 0; i < TM; ++i) a_addr[tt][i] += pdelta;
+                        pdelta = 0u - pdelta;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_half(I0{}, TNEXT{}, I0{}, slot);
+                }
+                mfma_half(I1{});
+                interleave_reads_with_mfmas();
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    } else {
+        // 1x1 tail slice: plain ring program
+        constexpr int SLOT = (BM + BN) * 64;
+        STAMP(1);
+        for (int it = 0; it < nkt; ++it) {
+            __builtin_amdgcn_s_barrier();
+            const f16* sA = smem + (it % TST) * SLOT;
+            const f16* sB = sA + BM * 64;
+            f16x8 xa[2][TM], wb[2][TN];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    xa[ks][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WTM + i * 16 + frag_row, ks * 4 + frag_chunk));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) wb[ks][j] = *reinterpret_cast<const f16x8*>(sB + ((b_off0 + j * 16 * 64) ^ (ks << 5)));
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(wb[ks][j], xa[ks][i], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+    wait_vmcnt<0>();
+    __syncthreads(); // all fragment reads done before the epilogue tile overwrites the ring
+    STAMP(2);
+
+    if (p.splits > 1) {
+        float* slab = p.partial + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + e_m;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + e_n;
+                if (n + 3 < p.N) {
+                    *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + n) = acc[i][j];
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N) slab[(size_t)m * p.N + n + r] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
+
+    const float alpha = p.alpha;
+    if (alpha != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] *= alpha;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * WTN + j * 16 + e_n;
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(colv + nl), b2 = *reinterpret_cast<const f32x4*>(colv + BN + nl);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] + b1[r]) + b2[r];
+    }
+    if (p.row_bias != nullptr) {
+        const bool rb_vec = (p.ldrb & 3) == 0 && ((uintptr_t)p.row_bias & 7) == 0 && (p.N & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + e_m;
+            const f16* rbias = p.row_bias + (size_t)((m < p.M ? m : 0) / p.rows_per_img) * p.ldrb;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + e_n;
+                if (rb_vec) {
+                    if (n < p.N) {
+                        const f16x4 t = *reinterpret_cast<const f16x4*>(rbias + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)t[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N) acc[i][j][r] += (float)rbias[n + r];
+                }
+            }
+        }
+    }
+    if (p.act != ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = apply_act(acc[i][j][r], p.act);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = wm * WTM + i * 16 + e_m;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn * WTN + j * 16 + e_n;
+            f16x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (f16)acc[i][j][r];
+            *reinterpret_cast<f16x4*>(sC + ml * SC + nl) = h;
+        }
+    }
+    __syncthreads();
+    STAMP(3);
+    store_phase();
+#ifdef SDOD_GEMM_STAMP
+    wait_vmcnt<0>();
+    STAMP(4);
+#endif
+}
+
 // Reduce split-K slabs and apply the fused epilogue.  One thread per 4 consecutive columns.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
     const int n4 = (p.N + 3) / 4;
@@ -1057,8 +1658,13 @@ const TileCfg kTiles[] = {{0, 0},     {128, 128}, {128, 64}, {64, 64},   {256, 1
                           // 23..31: wave-specialised LDS-DMA kernel (4 consumer + 4 loader waves)
                           {128, 128}, {128, 128}, {128, 256}, {256, 128}, {64, 64}, {64, 64}, {128, 64}, {64, 128}, {64, 160},
                           // 32..36: wave-specialised, two slabs per barrier
-                          {64, 64}, {128, 64}, {64, 128}, {64, 160}, {128, 128}};
-constexpr int kNumTiles = 36;
+                          {64, 64}, {128, 64}, {64, 128}, {64, 160}, {128, 128},
+                          // 37..45: halo-patch 3x3 convolution (conv_halo_kernel)
+                          {64, 160}, {128, 80}, {128, 160}, {64, 80}, {256, 32}, {128, 32}, {256, 64}, {128, 64}, {64, 64}};
+constexpr int kNumTiles = 45;
+constexpr int kFirstHaloTile = 37;
+// {STAGES} of the halo tiles (WM x WN is 2x2 for the 160- and 64-wide square-ish ones, 4x1 for the tall ones: launch switch)
+const int kHaloStages[] = {4, 4, 3, 4, 6, 6, 4, 4, 4};
 
 const f16* zero_line() { // one per device (the pointer is only valid on the device that allocated it)
     static std::atomic<f16*> z[64];
@@ -1093,6 +1699,20 @@ hipError_t launch_glds(const GemmP& p, dim3 grid, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <int BM, int BN, int WM, int WN, int STAGES>
+hipError_t launch_halo(const GemmP& p, dim3 grid, size_t smem, hipStream_t st) {
+    static std::atomic<unsigned long long> attr_devs{0};
+    if (sdod::first_use_on_device(attr_devs)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<BM, BN, WM, WN, STAGES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    const f16* z = zero_line();
+    if (!z) return hipErrorOutOfMemory;
+    SDOD_LAUNCH((conv_halo_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(512), smem, st, p, z);
+    return hipGetLastError();
+}
+
 template <int BM, int BN, int WM, int WN>
 hipError_t launch_cfg(const GemmP& p, dim3 grid, hipStream_t st) {
     constexpr size_t smem = (size_t)2 * (BM + BN) * 64 * sizeof(f16);
@@ -1110,7 +1730,58 @@ struct Plan {
     int tile;
     int splits;
     int kt_per_split;
+    int main_splits; // halo tiles: splits over the 3x3 taps (a fused 1x1 tail is one more)
 };
+
+// Can halo tile `tile` run descriptor d?  Fills the geometry fields of *p (may be null) and the LDS bytes of the launch.
+bool halo_geometry(const sdod_gemm_desc* d, int tile, GemmP* p, size_t* smem_bytes) {
+    if (tile < kFirstHaloTile || tile > kNumTiles) return false;
+    if (d->a_mode != SDOD_A_CONV3X3 || d->ksize == 1 || d->stride != 1 || d->upsample || d->wq || d->geglu || d->ln || d->bias_on_m) return false;
+    if (d->c0 <= 0 || d->c0 % 64 || d->c1 % 64 || d->h_in <= 0 || d->w_in <= 0 || d->n_img <= 0) return false;
+    const int BMt = kTiles[tile].bm, BNt = kTiles[tile].bn, stages = kHaloStages[tile - kFirstHaloTile];
+    const int H = d->h_in, W = d->w_in;
+    int tw, th, parts;
+    if (W >= BMt) {
+        if (W % BMt) return false;
+        tw = BMt; th = 1; parts = 1;
+    } else {
+        if (BMt % W) return false;
+        tw = W;
+        const int rows = BMt / W;
+        if (rows <= H) {
+            if (H % rows) return false;
+            th = rows; parts = 1;
+        } else {
+            if (rows % H) return false;
+            th = H; parts = rows / H;
+        }
+    }
+    const int pw = tw + 2, ppix = (th + 2) * pw, npix = parts * ppix;
+    const int nr = (npix * 8 + 255) / 256;
+    const int nrmax = BMt <= 64 ? 7 : BMt <= 128 ? 9 : 13;
+    if (nr > nrmax) return false;
+    const long long maxc = std::max(std::max(d->c0, d->c1), std::max(d->tc0, d->tc1));
+    if ((long long)d->n_img * H * W * maxc >= (1ll << 31)) return false;
+    const size_t patch_bytes = (size_t)nr * 256 * 16; // whole DMA rounds
+    const size_t halo = (size_t)stages * BNt * 128 + 2 * patch_bytes;
+    const size_t tail = d->k_tail ? (size_t)halo_tail_stages(BMt, BNt, stages) * (BMt + BNt) * 128 : 0;
+    const size_t ctile = (size_t)BMt * (BNt + 8) * sizeof(f16);
+    const size_t body = std::max(std::max(halo, tail), ctile);
+    const size_t total = body + (size_t)2 * BNt * sizeof(float);
+    if (total > 160 * 1024) return false;
+    if (smem_bytes) *smem_bytes = total;
+    if (p) {
+        p->h_tw = tw; p->h_th = th; p->h_pw = pw; p->h_ppix = ppix; p->h_npix = npix; p->h_nr = nr;
+        p->h_nimg = d->n_img;
+        p->h_patch_halves = (int)(patch_bytes / sizeof(f16));
+        p->h_colv_off = (int)body;
+        make_magic((unsigned)tw, &p->mg_tw, &p->sh_tw);
+        make_magic((unsigned)th, &p->mg_th, &p->sh_th);
+        make_magic((unsigned)pw, &p->mg_pw, &p->sh_pw);
+        make_magic((unsigned)ppix, &p->mg_pp, &p->sh_pp);
+    }
+    return true;
+}
 
 Plan make_plan(const sdod_gemm_desc* d) {
     Plan pl;
@@ -1146,6 +1817,23 @@ Plan make_plan(const sdod_gemm_desc* d) {
             if (splits > 32) splits = 32;
             if (splits < 1) splits = 1;
         }
+    }
+    pl.main_splits = 0;
+    if (tile >= kFirstHaloTile && halo_geometry(d, tile, nullptr, nullptr)) { // (a descriptor it cannot run is rejected at launch)
+        // whole 64-channel chunks (9 tap slabs) per split; the 1x1 tail, if any, is one more slice
+        const int nmain = (d->c0 + d->c1) / BK;
+        int want = d->split_k;
+        if (want <= 0) {
+            const int nt = ntiles(tile);
+            want = nt >= 192 ? 1 : (256 + nt / 2) / nt;
+        }
+        if (want > nmain) want = nmain;
+        if (want < 1) want = 1;
+        const int cps = (nmain + want - 1) / want;
+        pl.main_splits = (nmain + cps - 1) / cps;
+        pl.kt_per_split = 9 * cps;
+        pl.splits = pl.main_splits + (d->k_tail ? 1 : 0);
+        return pl;
     }
     if (splits > KT) splits = KT;
     if (splits < 1) splits = 1;
@@ -1196,6 +1884,14 @@ extern "C" __attribute__((visibility("default"))) int sdod_gemm_stamps(unsigned 
 }
 #endif
 
+#ifdef SDOD_GEMM_STAMP
+extern "C" __attribute__((visibility("default"))) int sdod_gemm_timeline(unsigned long long* out, int n_wg) {
+    if (!out || n_wg <= 0 || n_wg > 8192) return 1;
+    if (hipDeviceSynchronize() != hipSuccess) return 2;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), (size_t)n_wg * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 3;
+}
+#endif
+
 extern "C" int sdod_gemm_num_tiles(void) { return kNumTiles; }
 
 // template arguments of tile `tile` as the launch switch in sdod_gemm_f16 instantiates it: {BM, BN, WM, WN, STAGES (0 = the
@@ -1210,7 +1906,10 @@ extern "C" int sdod_gemm_tile_info(int tile, int out[7]) {
         {64, 160, 2, 2, 4, 0, 1}, {32, 160, 2, 2, 6, 0, 1},
         {128, 128, 2, 2, 4, 1, 1}, {128, 128, 2, 2, 3, 1, 1}, {128, 256, 2, 2, 3, 1, 1}, {256, 128, 2, 2, 3, 1, 1}, {64, 64, 2, 2, 8, 1, 1},
         {64, 64, 2, 2, 4, 1, 1}, {128, 64, 2, 2, 6, 1, 1}, {64, 128, 2, 2, 6, 1, 1}, {64, 160, 2, 2, 4, 1, 1},
-        {64, 64, 2, 2, 4, 1, 2}, {128, 64, 2, 2, 3, 1, 2}, {64, 128, 2, 2, 3, 1, 2}, {64, 160, 2, 2, 2, 1, 2}, {128, 128, 2, 2, 2, 1, 2}};
+        {64, 64, 2, 2, 4, 1, 2}, {128, 64, 2, 2, 3, 1, 2}, {64, 128, 2, 2, 3, 1, 2}, {64, 160, 2, 2, 2, 1, 2}, {128, 128, 2, 2, 2, 1, 2},
+        // SPEC column 2 = conv_halo_kernel<BM, BN, WM, WN, STAGES>
+        {64, 160, 2, 2, 4, 2, 1}, {128, 80, 4, 1, 4, 2, 1}, {128, 160, 2, 2, 3, 2, 1}, {64, 80, 4, 1, 4, 2, 1}, {256, 32, 4, 1, 6, 2, 1},
+        {128, 32, 4, 1, 6, 2, 1}, {256, 64, 4, 1, 4, 2, 1}, {128, 64, 2, 2, 4, 2, 1}, {64, 64, 2, 2, 4, 2, 1}};
     static_assert(sizeof(kInfo) / sizeof(kInfo[0]) == kNumTiles + 1, "one row per tile");
     if (tile < 1 || tile > kNumTiles || !out) return sdod::INVALID_ARGUMENT;
     for (int i = 0; i < 7; ++i) out[i] = kInfo[tile][i];
@@ -1305,9 +2004,14 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     }
     const Plan pl = make_plan(d);
     SDOD_REQUIRE(!(d->geglu && (pl.tile == 21 || pl.tile == 22 || pl.tile == 31 || pl.tile == 35)), "geglu needs a tile with an even number of 16-column blocks per wave");
-    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln || d->wq) || pl.tile >= 6, "geglu / tail segment / bias2 / ln / uint8 weights need an LDS-DMA tile (6..36)");
+    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln || d->wq) || pl.tile >= 6, "geglu / tail segment / bias2 / ln / uint8 weights need an LDS-DMA tile (6..45)");
     p.splits = pl.splits;
     p.kt_per_split = pl.kt_per_split;
+    size_t halo_smem = 0;
+    if (pl.tile >= kFirstHaloTile) {
+        SDOD_REQUIRE(halo_geometry(d, pl.tile, &p, &halo_smem), "this halo-patch tile does not take the convolution (3x3, stride 1, tile rows must divide the image)");
+        p.h_main_splits = pl.main_splits;
+    }
     if (pl.splits > 1) {
         SDOD_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= (size_t)pl.splits * d->M * d->N * sizeof(float),
                      "split-K workspace missing or too small");
@@ -1338,6 +2042,15 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     }
     else if (d->phase != 2)
     switch (pl.tile) {
+    case 37: e = launch_halo<64, 160, 2, 2, 4>(p, grid, halo_smem, st); break;
+    case 38: e = launch_halo<128, 80, 4, 1, 4>(p, grid, halo_smem, st); break;
+    case 39: e = launch_halo<128, 160, 2, 2, 3>(p, grid, halo_smem, st); break;
+    case 40: e = launch_halo<64, 80, 4, 1, 4>(p, grid, halo_smem, st); break;
+    case 41: e = launch_halo<256, 32, 4, 1, 6>(p, grid, halo_smem, st); break;
+    case 42: e = launch_halo<128, 32, 4, 1, 6>(p, grid, halo_smem, st); break;
+    case 43: e = launch_halo<256, 64, 4, 1, 4>(p, grid, halo_smem, st); break;
+    case 44: e = launch_halo<128, 64, 2, 2, 4>(p, grid, halo_smem, st); break;
+    case 45: e = launch_halo<64, 64, 2, 2, 4>(p, grid, halo_smem, st); break;
     case 1: e = launch_cfg<128, 128, 2, 2>(p, grid, st); break;
     case 2: e = launch_cfg<128, 64, 2, 2>(p, grid, st); break;
     case 3: e = launch_cfg<64, 64, 2, 2>(p, grid, st); break;

@@ -274,6 +274,77 @@ def test_conv3x3_with_skip_tail_segment(tile):
     check(out, ref, name=f'conv + skip tail tile{tile}')
 
 
+HALO_TILES = list(range(37, 46))
+
+
+def _halo_gemm(ops, *args, **kw):
+    """a halo-patch tile may decline a geometry (tile rows must divide the image, patch must fit LDS): skip, do not fail"""
+    try:
+        return ops.gemm(*args, **kw)
+    except Exception as ex:
+        if 'halo-patch tile does not take' in str(ex):
+            pytest.skip('tile declines this geometry')
+        raise
+
+
+@pytest.mark.parametrize('split', [0, 1, 3])
+@pytest.mark.parametrize('tile', HALO_TILES)
+@pytest.mark.parametrize('n,h,w,cin,cout', [
+    (2, 64, 64, 128, 320), (2, 32, 32, 192, 160), (2, 16, 16, 256, 256), (2, 8, 8, 320, 192), (1, 8, 8, 64, 64),
+    (3, 8, 8, 128, 80), (1, 128, 128, 64, 128), (5, 16, 16, 64, 48),
+])
+def test_conv3x3_halo_patch_tiles(n, h, w, cin, cout, tile, split):
+    """conv_halo_kernel (input patch resident in LDS, K walked chunk-major / tap-minor) against the fp32 convolution:
+    row-segment tiles (w >= BM), whole-row tiles, tiles spanning several images (and more images than the batch holds),
+    ragged N, uneven loader shares (BN = 80), one / default / three split-K slices"""
+    from sdod.amd import ops
+    x = rnd((n, h, w, cin), 120); wt = rnd((cout, 9 * cin), 121, (9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(122))
+    ref = conv_ref(x, wt, bias)
+    d = dev()
+    out = _halo_gemm(ops, x.to(d), wt.to(d), bias.to(d), conv=dict(stride=1), tile=tile, split_k=split)
+    check(out, ref, name=f'halo conv {n}x{h}x{w} {cin}->{cout} tile{tile} split{split}')
+
+
+@pytest.mark.parametrize('split', [1, 2])
+@pytest.mark.parametrize('tile', HALO_TILES)
+def test_conv3x3_halo_concat_rowbias_residual_tail(tile, split):
+    """everything a ResBlock asks of one launch: two-source channel concat, time-embedding row bias, SiLU-less epilogue with
+    residual, and the fused 1x1 skip connection as the extra split-K slice"""
+    from sdod.amd import ops
+    n, h, w, c0, c1, cout = 2, 16, 16, 128, 64, 192
+    x0 = rnd((n, h, w, c0), 130); x1 = rnd((n, h, w, c1), 131)
+    wt = rnd((cout, 9 * (c0 + c1)), 132, (9 * (c0 + c1)) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(133))
+    rb = torch.randn(n, cout, generator=torch.Generator().manual_seed(134)).half()
+    res = rnd((n, h, w, cout), 135)
+    ref = conv_ref(torch.cat([x0, x1], -1), wt, bias) + rb.float()[:, None, None, :]
+    ref = ref.half().float() + res.float()
+    d = dev()
+    out = _halo_gemm(ops, x0.to(d), wt.to(d), bias.to(d), a2=x1.to(d), conv=dict(stride=1), row_bias=rb.to(d), rows_per_img=h * w,
+                     residual=res.to(d), tile=tile, split_k=split)
+    check(out, ref, name=f'halo conv concat tile{tile} split{split}')
+    # conv2 + skip tail (k_tail): out = conv3x3(hmid) + b3 + [x0 | x1] @ w1^T + b1
+    cmid = 128
+    hmid = rnd((n, h, w, cmid), 136)
+    w3 = rnd((cmid, 9 * cmid), 137, (9 * cmid) ** -0.5); w1 = rnd((cmid, c0 + c1), 138, (c0 + c1) ** -0.5)
+    b3 = torch.randn(cmid, generator=torch.Generator().manual_seed(139)); b1 = torch.randn(cmid, generator=torch.Generator().manual_seed(140))
+    ref = conv_ref(hmid, w3, b3) + (torch.cat([x0, x1], -1).float() @ w1.float().t() + b1)
+    wcat = torch.cat([w3, w1], 1).contiguous()
+    out = _halo_gemm(ops, hmid.to(d), wcat.to(d), b3.to(d), conv=dict(stride=1), tail=(x0.to(d), x1.to(d)), bias2=b1.to(d), tile=tile, split_k=split)
+    check(out, ref, name=f'halo conv + skip tail tile{tile} split{split}')
+
+
+def test_halo_tiles_reject_what_they_cannot_run():
+    from sdod.amd import ops
+    d = dev()
+    x = rnd((2, 16, 16, 64), 141).to(d); wt = rnd((64, 9 * 64), 142, 0.05).to(d)
+    with pytest.raises(Exception):
+        ops.gemm(x, wt, None, conv=dict(stride=2), tile=38)            # stride 2
+    with pytest.raises(Exception):
+        ops.gemm(rnd((256, 64), 143).to(d), rnd((64, 64), 144).to(d), None, tile=38)   # rows mode
+
+
 def test_conv_small_cin_via_im2col():
     from sdod.amd import ops
     n, h, w, cin, cout = 2, 64, 64, 4, 320
