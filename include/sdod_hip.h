@@ -122,7 +122,9 @@ SDOD_API int sdod_gemm_time_cold(const sdod_gemm_desc* d, void* stream, int iter
 
 /* GroupNorm over NHWC [N][HW][C] (optionally the channel concat of x (c0) and x2 (c1)), G groups,
  * y = (x-mean)*rstd*w+b, optional SiLU.  dtype applies to x and y; weight/bias fp32 or NULL.
- * workspace: >= sdod_group_norm_workspace_bytes(N, G) bytes of fp32 scratch. */
+ * workspace: >= sdod_group_norm_workspace_bytes(N, G) bytes of fp32 scratch, ZEROED ONCE by its owner before the first call
+ * and never shared by two calls that may run concurrently (different streams: one workspace each): the one-launch kernel for
+ * big maps (>= 5 MB) keeps the words of its grid barrier at the end of it and leaves them re-armed. */
 SDOD_API size_t sdod_group_norm_workspace_bytes(int n, int groups);
 /* 1 = the single-launch kernel (whole image x channel set in LDS) handles this shape, 2 = statistics + apply launches */
 SDOD_API int sdod_group_norm_launches(int hw, int c, int groups, int dtype);

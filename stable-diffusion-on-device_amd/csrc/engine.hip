@@ -862,6 +862,7 @@ void Graph::finalize() {
     SDOD_HIP_CHECK(hipMalloc((void**)&arena_base_, arena_cap_));
     SDOD_HIP_CHECK(hipMalloc((void**)&ws_, ws_bytes_));
     SDOD_HIP_CHECK(hipMalloc((void**)&gn_ws_, gn_ws_bytes_));
+    SDOD_HIP_CHECK(hipMemset(gn_ws_, 0, gn_ws_bytes_)); // the one-launch GroupNorm keeps its grid-barrier words in here: zero once
     if (kind_ == SDOD_GRAPH_UNET && kv_total_ > 0)
         SDOD_HIP_CHECK(hipMalloc((void**)&kv_all_, (size_t)batch_ * cfg_.context_len * kv_total_ * sizeof(f16)));
     mode_ = REAL;

@@ -64,6 +64,7 @@ struct GnP {
     float* stats;   // [N][G][2] mean, rstd
     float* shift;   // [N][G] pilot value of every group, written by the statistics pass (the apply pass must not re-read x:
                     // with y == x another workgroup may already have overwritten pixel 0)
+    void* sync;     // grid-barrier words of the one-launch kernel for big maps (zeroed once by the workspace's owner)
     int N, HW, C0, C1, C, G, Cg;
     float eps;
     int silu;
@@ -822,6 +823,250 @@ static void gn2_launch(const GnP& q, hipStream_t st) {
     SDOD_HIP_CHECK(hipGetLastError());
 }
 
+constexpr int GN_MAX_CHUNKS_GRID = 256;
+
+// ------------------------------------------------------------------------------------------------
+// One-launch GroupNorm for the BIG fp16 maps (>= 5 MB): every CU streams whole pixel rows ONCE.
+//   The (image, group) kernel reads a group as Cg of every C channels -- 20 of every 640 bytes at 64x64 x 320 -- from only
+//   N*G = 64 workgroups (18-33 us for 10-30 MB); two launches that each read whole rows pay the launch + first-byte latency
+//   twice (the lean pair above: no faster).  Here one launch covers the chip with one workgroup per CU, image n owning
+//   wpi = (#CUs / N) of them; a workgroup loads its ppw pixels x C channels into REGISTERS (16-byte lanes, all loads in
+//   flight at once), reduces shifted sums per group, publishes them, meets the other workgroups at a grid barrier, reduces
+//   the wpi partials of its image in a fixed order (bit-reproducible), and normalises + stores from the registers.
+//   HBM/L2 traffic: x once, y once.
+//   Grid barrier: a small counter tree + generation words in the caller's workspace (sdod_group_norm_workspace_bytes;
+//   zeroed once by its owner, re-armed by every launch).  Every workgroup must be resident: the grid is at most one
+//   workgroup per CU (512 threads, < 32 KB LDS: several fit per CU, so a few such kernels on different streams still
+//   co-reside).  The wait is bounded: a launch that cannot meet (counter clobbered) gives up after ~2^21 polls instead
+//   of hanging the device.
+struct GnGridP {
+    const f16* x0;
+    const f16* x1;
+    f16* y;
+    const float* w;
+    const float* b;
+    float* partial;   // [N][wpi][G][2]
+    unsigned* sync;   // 25 words, one per 128-byte line: [0] top counter, [1..16] shard counters, [17..24] generation replicas
+    int N, HW, C0, C1, C, G, Cg;
+    int cp, rp;       // 16-byte chunks per pixel row; pixel rows per pass of the 512 threads
+    int wpi, ppw, nwg; // workgroups per image, pixels per workgroup, workgroups in the grid
+    float eps;
+    int silu;
+};
+
+template <int KMAX>
+__global__ __launch_bounds__(512) void gn_grid_kernel(const GnGridP p) {
+    __shared__ float red[512 * 4];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sc = reinterpret_cast<float*>(smem_raw); // [C] scale, [C] shift, [G] mean, [G] rstd
+    float* sh = sc + p.C;
+    float* gm = sh + p.C;
+    float* gr = gm + p.G;
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / p.wpi, wi = blockIdx.x - n * p.wpi;
+    unsigned gen0 = 0;
+    if (tid == 0) gen0 = __hip_atomic_load(p.sync + 32 * (17 + (blockIdx.x & 7)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // before this workgroup arrives
+    const bool active = tid < p.rp * p.cp;
+    const int r0 = tid / p.cp, j = tid - r0 * p.cp;
+    const int c0 = j * 8;
+    const int gA = c0 / p.Cg;
+    const int eb = min(8, (gA + 1) * p.Cg - c0); // channels [0, eb) of the chunk belong to group gA, the rest to gA + 1
+    const size_t row0 = (size_t)n * p.HW;
+    auto src = [&](size_t row, int c) { return c < p.C0 ? p.x0 + row * p.C0 + c : p.x1 + row * p.C1 + (c - p.C0); };
+    const int pix_begin = wi * p.ppw, pix_end = min(p.HW, pix_begin + p.ppw);
+    // pilot shift: the image's first pixel (read by every workgroup before any of them stores: y may be x)
+    const float shA = active ? (float)*src(row0, gA * p.Cg) : 0.f;
+    const float shB = (active && eb < 8) ? (float)*src(row0, (gA + 1) * p.Cg) : 0.f;
+    float pilot = 0.f;
+    if (tid < p.G) pilot = (float)*src(row0, tid * p.Cg);
+    f16x8 v[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int pix = pix_begin + r0 + k * p.rp;
+        v[k] = (active && pix < pix_end) ? ldg8(src(row0 + pix, c0)) : zero8();
+    }
+    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const bool ok = active && (pix_begin + r0 + k * p.rp) < pix_end;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool inA = e < eb;
+            const float d = ok ? (float)v[k][e] - (inA ? shA : shB) : 0.f;
+            a1 += inA ? d : 0.f; a2 += inA ? d * d : 0.f;
+            b1 += inA ? 0.f : d; b2 += inA ? 0.f : d * d;
+        }
+    }
+    red[tid * 4 + 0] = a1; red[tid * 4 + 1] = a2; red[tid * 4 + 2] = b1; red[tid * 4 + 3] = b2;
+    __syncthreads();
+    if (tid < p.G) {
+        const int g = tid;
+        const int j0 = (g * p.Cg) >> 3, j1 = ((g + 1) * p.Cg - 1) >> 3;
+        float s1 = 0.f, s2 = 0.f;
+        for (int jj = j0; jj <= j1; ++jj) {
+            const int first = (jj * 8) / p.Cg;      // group of the chunk's first channel
+            const int slot = first == g ? 0 : 2;    // else g is the chunk's second group
+            for (int r = 0; r < p.rp; ++r) {
+                s1 += red[(r * p.cp + jj) * 4 + slot];
+                s2 += red[(r * p.cp + jj) * 4 + slot + 1];
+            }
+        }
+        // cross-XCD hand-off WITHOUT fences (an agent-scope release writes back the whole L2 -- the previous GEMM's output --
+        // and cost ~35 us here): the payload is stored write-through (sc1: 8-byte agent-scope atomics, both sides), every storing
+        // wave waits for its stores, then ONE lane signals; readers poll the generation word with sc1 loads and read the
+        // payload with sc1 loads only (MI355X_MICROARCH.md, cross-workgroup hand-offs, first row of the table)
+        unsigned long long bits;
+        {
+            const float2 pr = {s1, s2};
+            __builtin_memcpy(&bits, &pr, 8);
+        }
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.partial) + ((size_t)n * p.wpi + wi) * p.G + g;
+        __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    // ---- grid barrier.  Atomics execute at the memory side, ~45 ns apiece on one address: 256 arrivals on ONE counter cost
+    // ~10 us, so arrivals go to 16 shard counters (one 128-byte line each), the last arrival of a shard reports to the top
+    // counter, and the last of those re-arms everything and publishes the new generation in 8 replicas (pollers spread over
+    // them; one poll per ~0.2 us so that 255 pollers do not eat the memory channel they share).  Measured alternatives
+    // (tools/gn_bench.py, 64x64 x 320, whole launch): one counter 16.5 us, this tree 13.4 us, a flag per workgroup polled by
+    // its readers 14.9 us (32 K polling loads per round on a handful of lines); the (image, group) kernel: 18.3 us.
+    if (tid == 0) {
+        const int shard = blockIdx.x & 15;
+        const unsigned in_shard = (unsigned)((p.nwg - shard + 15) >> 4);
+        bool opened = false;
+        unsigned prev = __hip_atomic_fetch_add(p.sync + 32 * (1 + shard), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1u == in_shard) {
+            __hip_atomic_store(p.sync + 32 * (1 + shard), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            prev = __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev + 1u == (unsigned)min(16, p.nwg)) {
+                __hip_atomic_store(p.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every counter is re-armed before anybody can leave
+                for (int r = 0; r < 8; ++r) __hip_atomic_store(p.sync + 32 * (17 + r), gen0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                opened = true;
+            }
+        }
+        if (!opened) {
+            const unsigned* flag = p.sync + 32 * (17 + (blockIdx.x & 7));
+            for (int spin = 0; spin < (1 << 20); ++spin) { // bounded: a clobbered workspace ends in wrong numbers, not in a hung device
+                if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen0) break;
+                __builtin_amdgcn_s_sleep(6);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- mean / rstd of every group of this image: 16 lanes per group, fixed order
+    {
+        const int g = tid >> 4, l = tid & 15;
+        float a = 0.f, b = 0.f;
+        if (g < p.G) {
+            for (int ch = l; ch < p.wpi; ch += 16) {
+                const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p.partial) + ((size_t)n * p.wpi + ch) * p.G + g,
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                float2 pr;
+                __builtin_memcpy(&pr, &bits, 8);
+                a += pr.x;
+                b += pr.y;
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            a += __shfl_xor(a, o);
+            b += __shfl_xor(b, o);
+        }
+        if (g < p.G && l == 0) {
+            const float cnt = (float)p.HW * (float)p.Cg;
+            const float md = a / cnt;
+            float var = b / cnt - md * md;
+            var = var < 0.f ? 0.f : var;
+            gm[g] = md; // + pilot, added below by the thread that holds it
+            gr[g] = 1.0f / sqrtf(var + p.eps);
+        }
+    }
+    __syncthreads();
+    if (tid < p.G) gm[tid] += pilot;
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 512) {
+        const int g = c / p.Cg;
+        const float wv = p.w ? p.w[c] : 1.0f, bv = p.b ? p.b[c] : 0.0f;
+        sc[c] = gr[g] * wv;
+        sh[c] = bv - gm[g] * gr[g] * wv;
+    }
+    __syncthreads();
+    if (!active) return;
+    float s8[8], t8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        s8[e] = sc[c0 + e];
+        t8[e] = sh[c0 + e];
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int pix = pix_begin + r0 + k * p.rp;
+        if (pix < pix_end) {
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)v[k][e] * s8[e] + t8[e];
+                if (p.silu) f = silu_f(f);
+                o[e] = (f16)f;
+            }
+            stg8(p.y + (row0 + pix) * p.C + c0, o);
+        }
+    }
+}
+
+// Smaller maps: the (image, group) kernel is as fast or faster -- the launch has a floor of ~11 us (a chain of ~8 fabric round
+// trips: first bytes, write-through partials, two counter hops, flag, poll, partial reads), tools/gn_bench.py
+constexpr size_t GN_GRID_MIN_BYTES = (size_t)5 << 20;
+
+static int gn_device_cus() { // per device, cached
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = -1;
+        cus[dev].store(v, std::memory_order_relaxed);
+    }
+    return v > 0 ? v : 0;
+}
+
+// vectors per thread the grid kernel would need (0: shape not taken)
+static int gn_grid_plan(int n, int hw, int c0, int c1, int groups, GnGridP* out) {
+    const int c = c0 + c1;
+    if (groups > 32 || n <= 0 || !gn2_fits(c0, c1, groups) || c / 8 > 512) return 0;
+    if ((size_t)n * hw * c * 2 < GN_GRID_MIN_BYTES) return 0;
+    int cus = gn_device_cus();
+    if (cus > 256) cus = 256;
+    const int wpi = cus / n;
+    if (wpi < 8 || wpi > GN_MAX_CHUNKS_GRID) return 0;
+    const int cp = c / 8, rp = 512 / cp;
+    const int ppw = (hw + wpi - 1) / wpi;
+    const int k = (ppw + rp - 1) / rp;
+    if (k > 16) return 0;
+    if (out) {
+        out->cp = cp; out->rp = rp; out->wpi = wpi; out->ppw = ppw; out->nwg = wpi * n;
+    }
+    return k <= 4 ? 4 : k <= 8 ? 8 : 16;
+}
+
+static bool gn_grid_try(const GnP& q, hipStream_t st) {
+    GnGridP p{};
+    const int kmax = gn_grid_plan(q.N, q.HW, q.C0, q.C1, q.G, &p);
+    if (!kmax) return false;
+    p.x0 = (const f16*)q.x0; p.x1 = (const f16*)q.x1; p.y = (f16*)q.y; p.w = q.w; p.b = q.b;
+    p.partial = q.partial;
+    p.sync = reinterpret_cast<unsigned*>(q.sync);
+    p.N = q.N; p.HW = q.HW; p.C0 = q.C0; p.C1 = q.C1; p.C = q.C; p.G = q.G; p.Cg = q.Cg; p.eps = q.eps; p.silu = q.silu;
+    const size_t smem = ((size_t)q.C * 2 + (size_t)q.G * 2) * sizeof(float);
+    if (kmax == 4) SDOD_LAUNCH((gn_grid_kernel<4>), dim3(p.nwg), dim3(512), smem, st, p);
+    else if (kmax == 8) SDOD_LAUNCH((gn_grid_kernel<8>), dim3(p.nwg), dim3(512), smem, st, p);
+    else SDOD_LAUNCH((gn_grid_kernel<16>), dim3(p.nwg), dim3(512), smem, st, p);
+    SDOD_HIP_CHECK(hipGetLastError());
+    return true;
+}
+
 static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 
 // single-launch path eligibility (also what sdod_group_norm_launches reports).  Up to 256 pixels a 256-thread workgroup
@@ -862,7 +1107,7 @@ constexpr int GN_INLINE_CHUNKS = 128; // up to here the apply pass reduces the p
 static int gn_path_override() {
     static const int v = [] {
         const char* e = std::getenv("SDOD_GN_PATH");
-        return !e ? 0 : e[0] == 'g' ? 1 : e[0] == 't' ? 2 : 0;
+        return !e ? 0 : e[0] == 'g' ? 1 : e[0] == 't' ? 2 : 0; // "group" also keeps the big maps off the grid-barrier kernel
     }();
     return v;
 }
@@ -879,6 +1124,7 @@ void gn_launch(GnP& p, hipStream_t st) {
         gn2_launch(p, st);
         return;
     }
+    if (sizeof(T) == 2 && gn_path_override() == 0 && gn_grid_try(p, st)) return;
     if (sizeof(T) == 2 && gn_group_try(p, nullptr, st)) return;
     if (gn_try_small<T>(p, st)) return;
     const int cp = p.C / 8;
@@ -1011,6 +1257,7 @@ extern "C" int sdod_group_norm_launches(int hw, int c, int groups, int dtype) {
     if (hw <= 0 || c <= 0 || groups <= 0 || c % groups) return 0;
     if (dtype == SDOD_F16 && groups <= 32 && gn2_fits(c, 0, groups) && gn_path_override() == 2) return 2;
     if (dtype == SDOD_F16 && c % 8 == 0 && gn_group_plan(hw, c, 0, c / groups, false).v && gn_path_override() != 2) return 1;
+    if (dtype == SDOD_F16 && gn_path_override() == 0 && gn_grid_plan(2, hw, c, 0, groups, nullptr)) return 1;
     return gn_small_fits(hw, c, c / groups, dtype == SDOD_F16 ? 2 : 4) ? 1 : 2; // (+1 collapse launch on very large maps)
 }
 
@@ -1048,7 +1295,7 @@ extern "C" int sdod_group_norm_reduce_nhwc(const sdod_gn_reduce* red, const void
 
 extern "C" size_t sdod_group_norm_workspace_bytes(int n, int groups) {
     if (n <= 0 || groups <= 0) return 0;
-    return ((size_t)n * GN_MAX_CHUNKS * groups * 2 + (size_t)n * groups * 3) * sizeof(float);
+    return ((size_t)n * GN_MAX_CHUNKS * groups * 2 + (size_t)n * groups * 3 + 32 * 26) * sizeof(float); // + the grid-barrier lines
 }
 
 extern "C" int sdod_group_norm_nhwc(const void* x, const void* x2, void* y, const float* weight, const float* bias, int n,
@@ -1080,6 +1327,7 @@ extern "C" int sdod_group_norm_nhwc(const void* x, const void* x2, void* y, cons
     p.partial = (float*)workspace;
     p.stats = p.partial + (size_t)n * GN_MAX_CHUNKS * groups * 2;
     p.shift = p.stats + (size_t)n * groups * 2;
+    p.sync = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(p.shift + (size_t)n * groups) + 127) & ~(uintptr_t)127); // 25 lines of 128 bytes
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SDOD_F16) gn_launch<f16>(p, st);
     else gn_launch<float>(p, st);

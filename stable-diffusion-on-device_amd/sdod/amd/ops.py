@@ -39,7 +39,8 @@ def workspace(nbytes, device, tag='default'):
     key = (device, tag)
     buf = _ws.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
-        buf = torch.empty((max(nbytes, 1) + 3) // 4, dtype=torch.float32, device=device)
+        # zeroed: the one-launch GroupNorm keeps its grid-barrier words at the end of its workspace (include/sdod_hip.h)
+        buf = torch.zeros((max(nbytes, 1) + 3) // 4, dtype=torch.float32, device=device)
         _ws[key] = buf
     return buf
 
