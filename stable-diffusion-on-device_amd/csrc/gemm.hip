@@ -67,6 +67,7 @@ struct GemmP {
     int wq;
     const float* w_scale;
     const float* w_off;
+    int lean; // plain row-major operands whose byte offsets fit 32 bits: the loaders take the short issue path
     // halo-patch convolution (conv_halo_kernel, tiles 37..): geometry of one workgroup's output tile and of the input patch
     // it keeps in LDS, all host-computed (halo_geometry)
     int h_tw, h_th;          // tile = h_tw consecutive pixels of h_th rows per part (h_tw == BM: a row segment; else whole rows)
@@ -359,6 +360,60 @@ SDOD_DEVICE void wait_younger(int y) {
     else if constexpr (Y > 0) wait_younger<LOADS, Y - 1>(y);
 }
 
+// Keep a wave-uniform value in an SGPR for good.  Kernel arguments are otherwise re-read from the kernarg segment (s_load)
+// wherever the register allocator finds that cheaper -- also inside main loops, where a pending scalar load forces every
+// following LDS wait to lgkmcnt(0) (SMEM returns out of order), i.e. kills the counted waits of a software pipeline.
+template <class T>
+SDOD_DEVICE T sgpr_pin(T v) {
+    if constexpr (sizeof(T) == 8) {
+        unsigned long long u = (unsigned long long)v;
+        asm volatile("" : "+s"(u));
+        return (T)u;
+    } else {
+        asm volatile("" : "+s"(v));
+        return v;
+    }
+}
+
+// conv_halo_kernel's loaders: patch DMA rounds (rpt in front of every slab at taps >= ahead, nrmax in all) that are issued
+// after the slab of tap ti and before the slab ahead slabs later, i.e. in front of taps ti+1 .. ti+ahead-1 of the same chunk
+constexpr int halo_rounds_between(int ti, int ahead, int nrmax, int rpt) {
+    int n = 0;
+    for (int u = ti + 1; u <= ti + ahead - 1 && u <= 8; ++u) {
+        if (u < ahead) continue;
+        int r = nrmax - rpt * (u - ahead);
+        r = r < 0 ? 0 : r > rpt ? rpt : r;
+        n += r;
+    }
+    return n;
+}
+
+// 16-byte-per-lane LDS-DMA issued BEHIND THE COMPILER'S BACK.  The waitcnt pass models global_load_lds as a FLAT access that
+// may touch LDS: while one is pending (and it cannot see the hand-counted s_waitcnt vmcnt that retire them) it turns every
+// LDS wait of the wave into lgkmcnt(0) -- a wave that both fetches by DMA and software-pipelines its fragment reads
+// (conv_halo_kernel's consumers) would wait for the fragments it has just requested.  lds_dst must be wave-uniform.
+SDOD_DEVICE void lds_dma16_opaque(const void* g, f16* lds_dst) {
+    const unsigned a = (unsigned)(uintptr_t)(lds_void_ptr)lds_dst;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(a) : "memory", "m0");
+}
+
+// 16-byte-per-lane LDS-DMA in the SADDR form: address = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset.
+// Three instructions per DMA (m0, the hazard nop, the load) and no vector arithmetic; the compiler's own selection of the
+// builtin spends two 64-bit vector adds per DMA on the same address.  base and lds_dst must be wave-uniform.
+SDOD_DEVICE void lds_dma16_saddr(const void* base, unsigned off, f16* lds_dst) {
+    const unsigned a = (unsigned)(uintptr_t)(lds_void_ptr)lds_dst;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(a) : "memory", "m0");
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <int N, int I = 0, class F>
+SDOD_DEVICE void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): n >= 32 waits for everything
 SDOD_DEVICE void wait_vmcnt_dyn(int n) {
     switch (n) {
@@ -536,11 +591,40 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
         }
     };
     const int cin = p.c0 + p.c1;
+    // LEAN issue path for plain row-major operands (every Linear of the graphs): the DMA address is a wave-uniform 64-bit base
+    // (operand + k, advanced in SGPRs once per slab) plus a per-lane 32-bit byte offset fixed for the whole kernel -- two or three
+    // instructions per DMA instead of the ~10 of the gather below.  (The loaders are instruction-bound, not bandwidth-bound:
+    // conv_halo_kernel's loaders went from 42 to 87-102 GB/s per CU when their per-DMA arithmetic was hoisted,
+    // profiles/r02_halo_phases.txt.)  Rows past M / N are CLAMPED to the last row instead of zero-filled: they only feed
+    // accumulators whose rows / columns the epilogue never stores.
+    const bool lean = p.lean != 0;
+    unsigned a_off[A_LD], b_off[B_LD];
+    auto setup_lean = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int m = min(m0 + (i * NL + lw) * 8 + lrow, p.M - 1);
+            a_off[i] = ((unsigned)m * (unsigned)p.lda + (unsigned)lchunk * 8u) * 2u;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int n = min(n0 + (i * NL + lw) * 8 + lrow, p.N - 1);
+            b_off[i] = ((unsigned)n * (unsigned)p.ldw + (unsigned)lchunk * 8u) * 2u;
+        }
+    };
 
     auto issue_tile = [&](int kt, int stage) {
         const int k0 = kt * BK;
         f16* sA = smem + stage * STAGE;
         f16* sB = sA + BM * 64;
+        if (lean) {
+            const f16* ab = p.a0 + k0;
+            const f16* wb = p.w + k0;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) lds_dma16_saddr(ab, a_off[i], sA + (i * NL + lw) * 8 * 64);
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) lds_dma16_saddr(wb, b_off[i], sB + (i * NL + lw) * 8 * 64);
+            return;
+        }
         if (p.k_tail && k0 >= p.k_tail) {
             // tail segment: the skip connection's 1x1 conv reads the block input at the OUTPUT pixel (centre tap)
             const int kk = k0 - p.k_tail;
@@ -691,7 +775,8 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
     if constexpr (SPEC) {
         if (!is_consumer) {
             // ---------------- LOADER program (complete; shares only the barriers with the consumers) ----------------
-            setup_rows();
+            if (lean) setup_lean();
+            else setup_rows();
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) rs1[i] = rs2[i] = 0.f;
 #pragma unroll
@@ -728,7 +813,8 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
 
     // ---------------- unified program (SPEC = false) / CONSUMER program (SPEC = true) ----------------
     if constexpr (!SPEC) {
-        setup_rows();
+        if (lean) setup_lean();
+        else setup_rows();
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) rs1[i] = rs2[i] = 0.f;
         // prologue: STAGES-1 slabs in flight
@@ -744,84 +830,152 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int it = 0; it < nkt; ++it) {
-        // slab `it` has landed once at most the younger in-flight slabs remain outstanding
-        if (it % KSUB == 0) {
-            if constexpr (!SPEC) wait_younger<LOADS, (STAGES - 2) * KSUB>(max(0, nkt - it - KSUB));
-            __builtin_amdgcn_s_barrier(); // everyone's slab group is in LDS; everyone is done reading the previous group
-        }
-
-        // fragment reads for the whole slab first, then the DMA issue for slab it+STAGES-1 (its address arithmetic and
-        // VMEM issue run under the LDS latency), then one uninterrupted MFMA cluster
-        const f16* sA = smem + (it % NSLOT) * STAGE;
-        const f16* sB = sA + BM * 64;
-        // Big consumer tiles (>= 32 accumulator quads: 128 registers) cannot also hold the fragments of both K halves of the
-        // slab: they read and multiply one half at a time (below); everyone else reads the whole slab first.
-        constexpr bool HALF_AT_A_TIME = TM * TN >= 32;
-        f16x8 xa[2][TM], wb[2][TN];
-        if (HALF_AT_A_TIME) {
-            // nothing to pre-read
-        } else if (!(dbg & 4) ) {
+    // Wave-specialised consumers of the small / medium tiles: SOFTWARE-PIPELINED K halves with the fragment reads INTERLEAVED
+    // between the MFMAs (as in conv_halo_kernel, where the same change took the consumer-only pace of a 128x80 tile from 0.33 to
+    // 0.28 us per slab): the reads of half h+1 are requested while half h is multiplied, across the slab boundary too
+    // (lgkmcnt(0) -> barrier -> next slab's first reads -> this slab's last MFMAs).  A wave issues in order and an MFMA holds
+    // its issue port for 8 of its 16 cycles, so a read placed between two MFMAs is free, while a block of reads in front of the
+    // MFMA block leaves the matrix pipe idle.  The consumers issue no vector-memory instruction, so the compiler can count
+    // the LDS waits (lgkmcnt(N)) once it knows nothing else is pending: the builtin wait for everything in front of the loop.
+    constexpr bool PIPELINED = SPEC && !WQ && TM * TN < 32 && dbg == 0;
+    if constexpr (PIPELINED) {
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        f16x8 fa[2][TM], fb[2][TN];
+        const unsigned smem_base = (unsigned)(uintptr_t)(lds_void_ptr)smem;
+        unsigned a_addr[TM];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int i = 0; i < TM; ++i) a_addr[i] = smem_base + (unsigned)lds_off(wm * WTM + i * 16 + frag_row, frag_chunk) * 2u;
+        const unsigned b_addr0 = smem_base + (unsigned)(BM * 64 + lds_off(wn * WTN + frag_row, frag_chunk)) * 2u;
+        auto lds16 = [](unsigned addr) { return *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>((uintptr_t)addr); };
+        auto read_half = [&](auto b_c, auto ks_c, int slot) {
+            constexpr int b = decltype(b_c)::value, ks = decltype(ks_c)::value;
+            const unsigned base = (unsigned)slot * (unsigned)(STAGE * 2);
+            const unsigned sb = (b_addr0 + base) ^ (ks << 6);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                xa[ks][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WTM + i * 16 + frag_row, ks * 4 + frag_chunk));
+            for (int i = 0; i < TM; ++i) fa[b][i] = lds16((a_addr[i] + base) ^ (ks << 6));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[b][j] = lds16(sb + j * 16 * 128);
+        };
+        auto mfma_half = [&](auto b_c) {
+            constexpr int b = decltype(b_c)::value;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                wb[ks][j] = WQ ? wq_frag(sB, wn * WTN + j * 16 + frag_row, ks, frag_chunk)
-                                 : *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
-        }
-        } else {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) xa[ks][i] = zero8();
-#pragma unroll
-                for (int j = 0; j < TN; ++j) wb[ks][j] = zero8();
+                for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(fb[b][j], fa[b][i], acc[i][j]);
+        };
+        auto interleave_reads_with_mfmas = [] { // scheduling directive for the region since the last sched_barrier
+            constexpr int NRD = TM + TN, NMF = TM * TN, PAIRS = NRD < NMF ? NRD : NMF;
+            __builtin_amdgcn_sched_group_barrier(0x002, TM + 3, 0); // the address arithmetic of the reads first
+            static_for<PAIRS>([](auto) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // one LDS read
+            });
+            if constexpr (NMF > PAIRS) __builtin_amdgcn_sched_group_barrier(0x008, NMF - PAIRS, 0);
+            if constexpr (NRD > PAIRS) __builtin_amdgcn_sched_group_barrier(0x100, NRD - PAIRS, 0);
+        };
+        __builtin_amdgcn_s_waitcnt(0); // (every counter: also retires the epilogue vectors' LDS-DMA, a "pending flat" to the compiler)
+        __builtin_amdgcn_s_barrier();  // the first slab group is in LDS (the loaders waited for it)
+        int slot = 0;
+        read_half(I0{}, I0{}, 0);
+        for (int it = 0; it < nkt; ++it) {
+            read_half(I1{}, I1{}, slot);
+            mfma_half(I0{});
+            interleave_reads_with_mfmas();
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 1 < nkt) {
+                if ((it + 1) % KSUB == 0) {
+                    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): my reads of this slab group are done, its slots may be refilled
+                    __builtin_amdgcn_s_barrier();
+                }
+                slot = slot + 1 == NSLOT ? 0 : slot + 1;
+                __builtin_amdgcn_sched_barrier(0);
+                read_half(I0{}, I0{}, slot);
             }
+            mfma_half(I1{});
+            interleave_reads_with_mfmas();
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (!SPEC) {
-            if (p.ln || WQ) ln_accumulate(sA);
-        }
-        if constexpr (!SPEC) {
-            if (it + AHEAD < nkt && !(dbg & 2)) issue_tile(kt_begin + it + AHEAD, (it + AHEAD) % NSLOT);
-        }
-        if (HALF_AT_A_TIME) {
-            {
-#pragma unroll
+    } else {
+        for (int it = 0; it < nkt; ++it) {
+            // slab `it` has landed once at most the younger in-flight slabs remain outstanding
+            if (it % KSUB == 0) {
+                if constexpr (!SPEC) wait_younger<LOADS, (STAGES - 2) * KSUB>(max(0, nkt - it - KSUB));
+                __builtin_amdgcn_s_barrier(); // everyone's slab group is in LDS; everyone is done reading the previous group
+            }
+
+            // fragment reads for the whole slab first, then the DMA issue for slab it+STAGES-1 (its address arithmetic and
+            // VMEM issue run under the LDS latency), then one uninterrupted MFMA cluster
+            const f16* sA = smem + (it % NSLOT) * STAGE;
+            const f16* sB = sA + BM * 64;
+            // Big consumer tiles (>= 32 accumulator quads: 128 registers) cannot also hold the fragments of both K halves of the
+            // slab: they read and multiply one half at a time (below); everyone else reads the whole slab first.
+            constexpr bool HALF_AT_A_TIME = TM * TN >= 32;
+            f16x8 xa[2][TM], wb[2][TN];
+            if (HALF_AT_A_TIME) {
+                // nothing to pre-read
+            } else if (!(dbg & 4) ) {
+    #pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+    #pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    xa[ks][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WTM + i * 16 + frag_row, ks * 4 + frag_chunk));
+    #pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    wb[ks][j] = WQ ? wq_frag(sB, wn * WTN + j * 16 + frag_row, ks, frag_chunk)
+                                     : *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
+            }
+            } else {
+    #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        xa[0][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WTM + i * 16 + frag_row, ks * 4 + frag_chunk));
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        wb[0][j] = WQ ? wq_frag(sB, wn * WTN + j * 16 + frag_row, ks, frag_chunk)
-                                        : *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(wb[0][j], xa[0][i], acc[i][j]);
-                    __builtin_amdgcn_sched_barrier(0); // keep the second half's fragment reads behind these MFMAs (registers)
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i) xa[ks][i] = zero8();
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j) wb[ks][j] = zero8();
                 }
             }
-        } else if (!(dbg & 1) ) {
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(wb[ks][j], xa[ks][i], acc[i][j]);
-            __builtin_amdgcn_s_setprio(0);
-        } else {
-            // keep the fragment reads alive without the matrix pipe
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(wb[ks][j]));
-#pragma unroll
-                for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(xa[ks][i]));
+            if constexpr (!SPEC) {
+                if (p.ln || WQ) ln_accumulate(sA);
+            }
+            if constexpr (!SPEC) {
+                if (it + AHEAD < nkt && !(dbg & 2)) issue_tile(kt_begin + it + AHEAD, (it + AHEAD) % NSLOT);
+            }
+            if (HALF_AT_A_TIME) {
+                {
+    #pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+    #pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            xa[0][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WTM + i * 16 + frag_row, ks * 4 + frag_chunk));
+    #pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            wb[0][j] = WQ ? wq_frag(sB, wn * WTN + j * 16 + frag_row, ks, frag_chunk)
+                                            : *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
+    #pragma unroll
+                        for (int j = 0; j < TN; ++j)
+    #pragma unroll
+                            for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(wb[0][j], xa[0][i], acc[i][j]);
+                        __builtin_amdgcn_sched_barrier(0); // keep the second half's fragment reads behind these MFMAs (registers)
+                    }
+                }
+            } else if (!(dbg & 1) ) {
+                __builtin_amdgcn_s_setprio(1);
+    #pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j)
+    #pragma unroll
+                        for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(wb[ks][j], xa[ks][i], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+                // keep the fragment reads alive without the matrix pipe
+    #pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(wb[ks][j]));
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(xa[ks][i]));
+                }
             }
         }
     }
@@ -1015,43 +1169,10 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
 #endif
 }
 
-// Keep a wave-uniform value in an SGPR for good.  Kernel arguments are otherwise re-read from the kernarg segment (s_load)
-// wherever the register allocator finds that cheaper -- also inside main loops, where a pending scalar load forces every
-// following LDS wait to lgkmcnt(0) (SMEM returns out of order), i.e. kills the counted waits of a software pipeline.
-template <class T>
-SDOD_DEVICE T sgpr_pin(T v) {
-    if constexpr (sizeof(T) == 8) {
-        unsigned long long u = (unsigned long long)v;
-        asm volatile("" : "+s"(u));
-        return (T)u;
-    } else {
-        asm volatile("" : "+s"(v));
-        return v;
-    }
-}
-
-// 16-byte-per-lane LDS-DMA issued BEHIND THE COMPILER'S BACK.  The waitcnt pass models global_load_lds as a FLAT access that
-// may touch LDS: while one is pending (and it cannot see the hand-counted s_waitcnt vmcnt that retire them) it turns every
-// LDS wait of the wave into lgkmcnt(0) -- a wave that both fetches by DMA and software-pipelines its fragment reads
-// (conv_halo_kernel's consumers) would wait for the fragments it has just requested.  lds_dst must be wave-uniform.
-SDOD_DEVICE void lds_dma16_opaque(const void* g, f16* lds_dst) {
-    const unsigned a = (unsigned)(uintptr_t)(lds_void_ptr)lds_dst;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(a) : "memory", "m0");
-}
-
 // ring depth of conv_halo_kernel's tail program: its slots hold A next to B, so fewer of them fit
 constexpr int halo_tail_stages(int bm, int bn, int stages) {
     const int fit = (150 * 1024) / ((bm + bn) * 128);
     return fit < stages ? fit : stages;
-}
-
-// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
-template <int N, int I = 0, class F>
-SDOD_DEVICE void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<N, I + 1>(f);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1190,21 +1311,27 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
         auto loader = [&](auto cnt_c) {
             constexpr int CNT = decltype(cnt_c)::value;
             constexpr int NB = CNT > 0 ? CNT : 1;
-            const f16* b_row[NB];
+            // weight rows: per-lane byte offset from the wave-uniform slab base (saddr DMA); rows past N are clamped to the last
+            // row -- they feed only columns the epilogue never stores
+            unsigned b_off[NB];
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int n = n0 + (i * NL + lw) * 8 + lrow;
-                b_row[i] = (i < CNT && n < p.N) ? p.w + (size_t)n * p.ldw + lchunk * 8 : zeros;
+                const int n = min(n0 + (i * NL + lw) * 8 + lrow, p.N - 1);
+                b_off[i] = ((unsigned)n * (unsigned)p.ldw + (unsigned)lchunk * 8u) * 2u;
             }
+            const f16* w_s = sgpr_pin(p.w);
             if (!tail_wg) {
                 constexpr int SLOT = BN * 64;
-                // ---- the patch pieces this lane fetches (one 16-byte piece per DMA round), as input pixel indices (-1: zero halo)
+                // ---- the patch pieces this lane fetches (one 16-byte piece per DMA round): byte offset inside either source,
+                // validity bit (zero halo, pixels past the patch, images past the batch: those lanes read the zero line).
+                // ALWAYS NRMAX rounds -- rounds past the patch move zeros into spare LDS -- so that every wait count below is a
+                // compile-time constant (a skipped DMA would make the counted waits under-wait).
                 const int hw = p.h_out * p.w_out;
                 const int img0 = fast_div(m0, p.mg_hw, p.sh_hw);
                 const int rem0 = m0 - img0 * hw;
                 const int y0 = fast_div(rem0, p.mg_w, p.sh_w);
                 const int x0 = rem0 - y0 * p.w_out;
-                int poff[NRMAX];
+                unsigned boff0[NRMAX], boff1[NRMAX], vmask = 0;
 #pragma unroll
                 for (int j = 0; j < NRMAX; ++j) {
                     const int pix = (j * 256 + lw * 64 + lane) >> 3;
@@ -1214,20 +1341,21 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
                     const int px = r2 - py * p.h_pw;
                     const int gy = y0 - 1 + py, gx = x0 - 1 + px, img = img0 + part;
                     const bool ok = pix < p.h_npix && img < p.h_nimg && (unsigned)gy < (unsigned)p.h_in && (unsigned)gx < (unsigned)p.w_in;
-                    poff[j] = ok ? (img * p.h_in + gy) * p.w_in + gx : -1;
+                    const unsigned gp = ok ? (unsigned)((img * p.h_in + gy) * p.w_in + gx) : 0u;
+                    boff0[j] = (gp * (unsigned)p.sa0 + (unsigned)lchunk * 8u) * 2u;
+                    boff1[j] = (gp * (unsigned)p.sa1 + (unsigned)lchunk * 8u) * 2u;
+                    vmask |= (ok ? 1u : 0u) << j;
                 }
-                const int c0_s = sgpr_pin(p.c0), sa0_s = sgpr_pin(p.sa0), sa1_s = sgpr_pin(p.sa1), nr_s = sgpr_pin(p.h_nr);
-                const int ph_s = sgpr_pin(p.h_patch_halves), cin_s = sgpr_pin(cin);
-                const f16* a0_s = sgpr_pin(p.a0);
-                const f16* a1_s = sgpr_pin(p.a1);
+                const int c0_s = sgpr_pin(p.c0), ph_s = sgpr_pin(p.h_patch_halves), cin_s = sgpr_pin(cin);
+                const unsigned long long a0_s = sgpr_pin((unsigned long long)p.a0), a1_s = sgpr_pin((unsigned long long)p.a1);
+                const unsigned long long z_s = sgpr_pin((unsigned long long)zeros);
                 auto issue_patch = [&](int chunk, int buf, auto j_c) { // chunk, buf wave-uniform
                     constexpr int j = decltype(j_c)::value;
                     const int cc = chunk * BK;
                     const bool second = cc >= c0_s;
-                    const f16* src = second ? a1_s : a0_s;
-                    const int sa = second ? sa1_s : sa0_s;
-                    const int ccs = (second ? cc - c0_s : cc) + lchunk * 8;
-                    const f16* g = poff[j] >= 0 ? src + poff[j] * sa + ccs : zeros;
+                    const unsigned long long base = (second ? a1_s : a0_s) + (unsigned long long)((second ? cc - c0_s : cc) * 2);
+                    const unsigned long long a = base + (second ? boff1[j] : boff0[j]);
+                    const unsigned long long g = ((vmask >> j) & 1u) ? a : z_s;
                     f16* dst = smem + STAGES * SLOT + buf * ph_s + (j * 256 + lw * 64) * 8;
                     __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)dst, 16, 0, 0);
                 };
@@ -1236,56 +1364,51 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
                 // chunk c-1, whose buffer the rounds overwrite).  Everything issued in front of slab 9(c+1) -- all of the patch
                 // -- has landed when that slab has (vmcnt retires in order), so the one counted wait per slab covers both.
                 constexpr int RPT = (NRMAX + (9 - AHEAD) - 1) / (9 - AHEAD);
-                static_assert(AHEAD < 9 && (B_LDX + RPT) * (AHEAD - 1) < 32, "patch rounds per tap / wait table");
-                auto rounds_at = [&](int t) { return t < AHEAD ? 0 : max(0, min(RPT, nr_s - RPT * (t - AHEAD))); }; // DMA rounds in front of tap t
+                static_assert(AHEAD < 9 && (B_LDX + RPT) * (AHEAD - 1) + RPT < 64, "vmcnt is a 6-bit counter");
                 const int chunk_begin = kt_begin / 9, chunk_end = kt_end / 9;
                 int k0 = chunk_begin * BK;  // weight column of the next slab to issue: tap * cin + chunk * 64
                 int s_slot = 0;             // ... and its ring slot
-                static_for<NRMAX>([&](auto j_c) {
-                    if (decltype(j_c)::value < nr_s) issue_patch(chunk_begin, 0, j_c);
-                });
+                static_for<NRMAX>([&](auto j_c) { issue_patch(chunk_begin, 0, j_c); });
                 STAMP(1);
-                // s = slab to issue, it = s - AHEAD = slab whose barrier is due; nine taps unrolled, so taps are compile-time
-                for (int c = chunk_begin; c <= chunk_end; ++c) { // (the extra pass only drains the last AHEAD barriers)
-                    const bool has_next = c + 1 < chunk_end;
-                    const int s_base = (c - chunk_begin) * 9;
+                // slabs of chunk c; slab (c, t) is issued after the barrier of the slab AHEAD before it.  LAST: no next patch.
+                auto pass = [&](auto last_c, int c, bool first) {
+                    constexpr bool LAST = decltype(last_c)::value;
                     static_for<9>([&](auto t_c) {
                         constexpr int t = decltype(t_c)::value;
-                        const int sidx = s_base + t, it = sidx - AHEAD;
-                        if (it >= 0 && it < nkt) {
-                            // DMA instructions younger than slab `it`: the slabs it+1 .. it+AHEAD-1 and the patch rounds in front of them
-                            constexpr int ti = (t + 9 - AHEAD) % 9;                   // tap of slab `it`
-                            int young = min(AHEAD - 1, nkt - it - 1) * CNT;
-                            // rounds ride only on taps >= AHEAD of the chunk slab `it` belongs to (a wrap lands on taps < AHEAD: none)
-                            const bool it_has_next = (t >= AHEAD ? c : c - 1) + 1 < chunk_end;
-                            if (it_has_next) {
-#pragma unroll
-                                for (int u = ti + 1; u <= ti + AHEAD - 1 && u <= 8; ++u) young += rounds_at(u);
-                            }
-                            if (dbg & 32) wait_vmcnt<0>();
-                            else wait_vmcnt_dyn(young);
+                        if (t >= AHEAD || !first) {
+                            // DMA instructions younger than the slab whose barrier is due (tap ti): AHEAD-1 weight slabs and the
+                            // patch rounds in front of those of them that sit at taps >= AHEAD of a chunk with a successor
+                            constexpr int ti = (t + 9 - AHEAD) % 9;
+                            constexpr bool rounds = !(LAST && t >= AHEAD); // (t < AHEAD: the due slab belongs to chunk c-1)
+                            constexpr int young = (AHEAD - 1) * CNT + (rounds ? halo_rounds_between(ti, AHEAD, NRMAX, RPT) : 0);
+                            if (dbg & (16 | 32)) wait_vmcnt<0>();
+                            else wait_vmcnt<young>();
                             if (!(dbg & 128)) __builtin_amdgcn_s_barrier();
                         }
-                        if (sidx < nkt && !((dbg & 32) && sidx >= AHEAD)) {
-                            if (t >= AHEAD && has_next && !(dbg & 16)) {
+                        if ((dbg & 32) && !(first && t < AHEAD)) return;
+                        if constexpr (!LAST && t >= AHEAD) {
+                            if (!(dbg & 16)) {
                                 static_for<RPT>([&](auto r_c) {
                                     constexpr int j = RPT * (t - AHEAD) + decltype(r_c)::value;
-                                    if constexpr (j >= 0 && j < NRMAX) {
-                                        if (j < nr_s) issue_patch(c + 1, (c + 1 - chunk_begin) & 1, std::integral_constant<int, j>{});
-                                    }
+                                    if constexpr (j < NRMAX) issue_patch(c + 1, (c + 1 - chunk_begin) & 1, std::integral_constant<int, j>{});
                                 });
                             }
-                            f16* sB = smem + s_slot * SLOT;
-#pragma unroll
-                            for (int i = 0; i < CNT; ++i) {
-                                const f16* g = b_row[i] + (b_row[i] == zeros ? 0 : k0);
-                                __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * NL + lw) * 8 * 64), 16, 0, 0);
-                            }
-                            k0 += t == 8 ? BK - 8 * cin_s : cin_s;
-                            s_slot = s_slot + 1 == STAGES ? 0 : s_slot + 1;
                         }
+                        f16* sB = smem + s_slot * SLOT;
+#pragma unroll
+                        for (int i = 0; i < CNT; ++i) lds_dma16_saddr(w_s + k0, b_off[i], sB + (i * NL + lw) * 8 * 64);
+                        k0 += t == 8 ? BK - 8 * cin_s : cin_s;
+                        s_slot = s_slot + 1 == STAGES ? 0 : s_slot + 1;
                     });
-                }
+                };
+                for (int c = chunk_begin; c + 1 < chunk_end; ++c) pass(std::false_type{}, c, c == chunk_begin);
+                pass(std::true_type{}, chunk_end - 1, chunk_begin + 1 == chunk_end);
+                static_for<AHEAD>([&](auto t_c) { // the barriers of the last AHEAD slabs: only weight slabs are younger
+                    constexpr int t = decltype(t_c)::value;
+                    if (dbg & (16 | 32)) wait_vmcnt<0>();
+                    else wait_vmcnt<(AHEAD - 1 - t) * CNT>();
+                    if (!(dbg & 128)) __builtin_amdgcn_s_barrier();
+                });
             } else {
                 // 1x1 tail: plain [BM][64] A slabs (the centre pixel of each output row) next to the weight slab
                 constexpr int SLOT = (BM + BN) * 64;
@@ -1310,10 +1433,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
                     }
                     const int k0 = p.k_tail + kk;
 #pragma unroll
-                    for (int i = 0; i < CNT; ++i) {
-                        const f16* g = b_row[i] + (b_row[i] == zeros ? 0 : k0);
-                        __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(sB + (i * NL + lw) * 8 * 64), 16, 0, 0);
-                    }
+                    for (int i = 0; i < CNT; ++i) lds_dma16_saddr(w_s + k0, b_off[i], sB + (i * NL + lw) * 8 * 64);
                 };
 #pragma unroll
                 for (int s = 0; s < TAHEAD; ++s)
@@ -1726,6 +1846,11 @@ hipError_t launch_cfg(const GemmP& p, dim3 grid, hipStream_t st) {
     return hipGetLastError();
 }
 
+bool lean_disabled() { // SDOD_GEMM_LEAN_OFF=1: developer switch (A/B timing of the short issue path)
+    static const bool off = std::getenv("SDOD_GEMM_LEAN_OFF") != nullptr;
+    return off;
+}
+
 struct Plan {
     int tile;
     int splits;
@@ -1762,7 +1887,7 @@ bool halo_geometry(const sdod_gemm_desc* d, int tile, GemmP* p, size_t* smem_byt
     if (nr > nrmax) return false;
     const long long maxc = std::max(std::max(d->c0, d->c1), std::max(d->tc0, d->tc1));
     if ((long long)d->n_img * H * W * maxc >= (1ll << 31)) return false;
-    const size_t patch_bytes = (size_t)nr * 256 * 16; // whole DMA rounds
+    const size_t patch_bytes = (size_t)nrmax * 256 * 16; // the loaders always issue the tile's maximum of DMA rounds
     const size_t halo = (size_t)stages * BNt * 128 + 2 * patch_bytes;
     const size_t tail = d->k_tail ? (size_t)halo_tail_stages(BMt, BNt, stages) * (BMt + BNt) * 128 : 0;
     const size_t ctile = (size_t)BMt * (BNt + 8) * sizeof(f16);
@@ -2002,6 +2127,8 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         p.c0 = d->K; p.c1 = 0; p.h_in = p.w_in = p.h_out = p.w_out = 1; p.stride = 1; p.ksize = 1;
         p.sa0 = d->lda; p.sa1 = 0;
     }
+    p.lean = (d->a_mode == SDOD_A_ROWS && !d->wq && !d->k_tail && (unsigned long long)d->M * d->lda * 2 < (1ull << 32) &&
+              (unsigned long long)d->N * d->ldw * 2 < (1ull << 32) && !lean_disabled()) ? 1 : 0;
     const Plan pl = make_plan(d);
     SDOD_REQUIRE(!(d->geglu && (pl.tile == 21 || pl.tile == 22 || pl.tile == 31 || pl.tile == 35)), "geglu needs a tile with an even number of 16-column blocks per wave");
     SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln || d->wq) || pl.tile >= 6, "geglu / tail segment / bias2 / ln / uint8 weights need an LDS-DMA tile (6..45)");

@@ -49,6 +49,7 @@ def main():
     ap.add_argument('--tiles', default='13,9,8,21')
     ap.add_argument('--split', type=int, default=1)
     ap.add_argument('--residual', action='store_true')
+    ap.add_argument('--geglu', action='store_true', help='rows shapes: fused GEGLU epilogue (N = 2 x hidden, [value | gate] 16-column blocks)')
     ap.add_argument('--timeline', action='store_true', help='halo tiles: shader-clock timeline of main-loop iterations 20 and 21 of consumer wave 0')
     args = ap.parse_args()
     lib = _lib.hip()
@@ -77,6 +78,8 @@ def main():
         bias = torch.randn(n).to(d)
         if args.residual:
             kw['residual'] = torch.randn(res_shape, generator=g).half().to(d)
+        if args.geglu and kind == 'rows':
+            kw['geglu'] = True
         for t in tiles:
             try:
                 for _ in range(3):
