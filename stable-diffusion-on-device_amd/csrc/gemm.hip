@@ -1339,7 +1339,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
                     const int r2 = pix - part * p.h_ppix;
                     const int py = fast_div(r2, p.mg_pw, p.sh_pw);
                     const int px = r2 - py * p.h_pw;
-                    const int gy = y0 - 1 + py, gx = x0 - 1 + px, img = img0 + part;
+                    // patch origin in the source image: one pixel above / left of the tile (upsampling: of its pre-image)
+                    const int gy = (p.ups ? (y0 - 1) >> 1 : y0 - 1) + py, gx = (p.ups ? (x0 - 1) >> 1 : x0 - 1) + px, img = img0 + part;
                     const bool ok = pix < p.h_npix && img < p.h_nimg && (unsigned)gy < (unsigned)p.h_in && (unsigned)gx < (unsigned)p.w_in;
                     const unsigned gp = ok ? (unsigned)((img * p.h_in + gy) * p.w_in + gx) : 0u;
                     boff0[j] = (gp * (unsigned)p.sa0 + (unsigned)lchunk * 8u) * 2u;
@@ -1477,6 +1478,13 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
         // pixel (row + tap shift) * 128 + swizzled 16-byte piece.  Nine taps unrolled below, so these are plain registers;
         // the other K half is the same address with bit 6 flipped, the other patch buffer a constant further.
         const unsigned smem_base = (unsigned)(uintptr_t)(lds_void_ptr)smem;
+        int ty0 = 0, tx0 = 0; // first output pixel of the tile (only the upsampling address map needs it)
+        if (p.ups) {
+            const int img0 = fast_div(m0, p.mg_hw, p.sh_hw);
+            const int rem0 = m0 - img0 * (p.h_out * p.w_out);
+            ty0 = fast_div(rem0, p.mg_w, p.sh_w);
+            tx0 = rem0 - ty0 * p.w_out;
+        }
         unsigned a_addr[9][TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -1484,10 +1492,17 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
             const int ly = fast_div(r, p.mg_tw, p.sh_tw);
             const int lx = r - ly * p.h_tw;
             const int part = fast_div(ly, p.mg_th, p.sh_th);
-            const int abase = part * p.h_ppix + (ly - part * p.h_th) * p.h_pw + lx; // patch pixel under tap (0, 0)
+            const int lyy = ly - part * p.h_th;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int pix = abase + (t / 3) * p.h_pw + t % 3;
+                // patch pixel under tap t of this output pixel; with nearest-2x upsampling folded in, output (y, x) reads source
+                // (y >> 1, x >> 1) and the patch origin is the pre-image of the pixel above / left of the tile
+                int sy = lyy + t / 3, sx = lx + t % 3;
+                if (p.ups) {
+                    sy = ((ty0 + lyy + t / 3 - 1) >> 1) - ((ty0 - 1) >> 1);
+                    sx = ((tx0 + lx + t % 3 - 1) >> 1) - ((tx0 - 1) >> 1);
+                }
+                const int pix = part * p.h_ppix + sy * p.h_pw + sx;
                 a_addr[t][i] = smem_base + (unsigned)(STAGES * SLOT * 2) + (unsigned)(pix * 128 + ((frag_chunk ^ (pix & 7)) << 4));
             }
         }
@@ -1861,10 +1876,12 @@ struct Plan {
 // Can halo tile `tile` run descriptor d?  Fills the geometry fields of *p (may be null) and the LDS bytes of the launch.
 bool halo_geometry(const sdod_gemm_desc* d, int tile, GemmP* p, size_t* smem_bytes) {
     if (tile < kFirstHaloTile || tile > kNumTiles) return false;
-    if (d->a_mode != SDOD_A_CONV3X3 || d->ksize == 1 || d->stride != 1 || d->upsample || d->wq || d->geglu || d->ln || d->bias_on_m) return false;
+    if (d->a_mode != SDOD_A_CONV3X3 || d->ksize == 1 || d->stride != 1 || d->wq || d->geglu || d->ln || d->bias_on_m) return false;
     if (d->c0 <= 0 || d->c0 % 64 || d->c1 % 64 || d->h_in <= 0 || d->w_in <= 0 || d->n_img <= 0) return false;
+    if (d->upsample && d->k_tail) return false;
     const int BMt = kTiles[tile].bm, BNt = kTiles[tile].bn, stages = kHaloStages[tile - kFirstHaloTile];
-    const int H = d->h_in, W = d->w_in;
+    const int ups = d->upsample ? 1 : 0;
+    const int H = d->h_in << ups, W = d->w_in << ups; // OUTPUT size: the tile lives there, the patch in the (smaller) source
     int tw, th, parts;
     if (W >= BMt) {
         if (W % BMt) return false;
@@ -1881,7 +1898,10 @@ bool halo_geometry(const sdod_gemm_desc* d, int tile, GemmP* p, size_t* smem_byt
             th = H; parts = rows / H;
         }
     }
-    const int pw = tw + 2, ppix = (th + 2) * pw, npix = parts * ppix;
+    // nearest-2x upsampling folded in: the patch is cut from the SOURCE image -- output rows y0-1 .. y0+th map onto source rows
+    // (y0-1)>>1 .. (y0+th)>>1, i.e. th/2 + 2 of them (th even, or one output row: 2); same for columns
+    if (ups && ((th > 1 && (th & 1)) || (tw & 1))) return false;
+    const int pw = (ups ? tw / 2 : tw) + 2, ppix = ((ups ? th / 2 : th) + 2) * pw, npix = parts * ppix;
     const int nr = (npix * 8 + 255) / 256;
     const int nrmax = BMt <= 64 ? 7 : BMt <= 128 ? 9 : 13;
     if (nr > nrmax) return false;

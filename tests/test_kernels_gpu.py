@@ -335,6 +335,21 @@ def test_conv3x3_halo_concat_rowbias_residual_tail(tile, split):
     check(out, ref, name=f'halo conv + skip tail tile{tile} split{split}')
 
 
+@pytest.mark.parametrize('split', [0, 2])
+@pytest.mark.parametrize('tile', HALO_TILES)
+@pytest.mark.parametrize('n,h,w,cin,cout', [(2, 32, 32, 128, 160), (2, 16, 16, 192, 128), (1, 8, 8, 128, 128), (3, 4, 4, 64, 80), (1, 64, 64, 64, 64)])
+def test_conv3x3_halo_patch_tiles_with_upsampling(n, h, w, cin, cout, tile, split):
+    """Upsample.conv: nearest-2x folded into the halo-patch kernel -- the patch is cut from the low-resolution source and the
+    per-tap fragment addresses map output (y, x) onto source (y >> 1, x >> 1)"""
+    from sdod.amd import ops
+    x = rnd((n, h, w, cin), 150); wt = rnd((cout, 9 * cin), 151, (9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(152))
+    ref = conv_ref(x, wt, bias, 1, True)
+    d = dev()
+    out = _halo_gemm(ops, x.to(d), wt.to(d), bias.to(d), conv=dict(stride=1, upsample=True), tile=tile, split_k=split)
+    check(out, ref, name=f'halo upconv {n}x{h}x{w} {cin}->{cout} tile{tile} split{split}')
+
+
 def test_halo_tiles_reject_what_they_cannot_run():
     from sdod.amd import ops
     d = dev()
