@@ -82,6 +82,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--images-per-gpu', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--overlap-decode', action='store_true', help='experiment: decode image i on a side stream while image i+1 is sampled (measured slower)')
     ap.add_argument('--no-hip-graph', action='store_true')
     ap.add_argument('--sampler', default='plms', choices=['plms', 'dpm'], help="plms: the headline workload (config 3); dpm: the reference "
                     "driver's DPM-Solver++(2M), e.g. --sampler dpm --sampler-steps 50 --images-per-gpu 2 = one rank's share of config 4")
@@ -185,6 +186,11 @@ def main():
         ctx2 = broadcast_conditioning(ctx2, 0)
         if args.per_step_launches or args.no_hip_graph:
             return pipe.generate(ctx2, x_T, steps=args.sampler_steps, guidance=7.5, sampler=args.sampler)
+        if args.overlap_decode:
+            # experiment: the VAE decode of this image on a side stream under the sampling of the next one (every image is
+            # complete when the timed region's closing synchronize returns).  Measured SLOWER than the serial form on MI355X
+            # (8.97 vs 9.29 images/s on one box): the decode's big grids take CUs from the latency-bound UNet chain
+            return pipe.generate_pipelined(ctx2, x_T, steps=args.sampler_steps, guidance=7.5, sampler=args.sampler)[0]
         return pipe.generate_graphed(ctx2, x_T, steps=args.sampler_steps, guidance=7.5, sampler=args.sampler)
 
     def barrier():
@@ -312,7 +318,8 @@ def main():
                        'images_per_gpu': n, 'global_batch': n * (world // 2 if args.cfg_split else world), 'parallelism': (f'dp{world // 2} x cfg-split pairs (1 broadcast + 1 all-gather per UNet evaluation)' if args.cfg_split
                                        else f'dp{world} (image shards, 1 RCCL broadcast)'),
                        'hip_graph': not args.no_hip_graph,
-                       'trajectory_graph': not (args.per_step_launches or args.no_hip_graph)},
+                       'trajectory_graph': not (args.per_step_launches or args.no_hip_graph),
+                       'decode_overlaps_next_sampling': bool(args.overlap_decode) and not (args.per_step_launches or args.no_hip_graph)},
             'unet_step_ms': round(unet_step_ms, 3),
             'roofline': roof,
             'setup_s': round(setup_s, 1),

@@ -229,6 +229,58 @@ class Txt2Img:
         g.replay()
         return out
 
+    def generate_pipelined(self, ctx2, x_T, steps=20, guidance=7.5, sampler='plms'):
+        """generate_graphed() as TWO device graphs -- sampling (context upload, every UNet evaluation, CFG, sampler updates) on
+        the current stream and decoding (VAE + uint8) on a side stream -- so that the decode of image i runs while image i+1 is
+        being sampled.  EXPERIMENT, not the default: the guided UNet chain is latency-bound (batch 1 takes 82 % of the time of
+        batch 2, tools/two_chain_probe.py), but on MI355X the decode's big grids take more from that chain than the overlap
+        gives back (bench.py --overlap-decode: 8.97 vs 9.29 images/s serial, same box).  Returns (uint8 images, event): the
+        images are valid once the event has completed and until the decode of the NEXT call starts."""
+        if self.cfg_split:
+            out = self.generate(ctx2, x_T, steps, guidance, sampler)
+            ev = torch.cuda.Event(); ev.record()
+            return out, ev
+        key = ('pipelined', sampler, int(steps), float(guidance), tuple(x_T.shape))
+        cache = self.__dict__.setdefault('_traj', {})
+        mode = 1 if sampler == 'plms' else 0
+        if key not in cache:
+            s_ctx = torch.empty_like(ctx2, device=self.device)
+            s_x = torch.empty(tuple(x_T.shape), dtype=torch.float32, device=self.device)
+            s_ctx.copy_(ctx2); s_x.copy_(x_T)
+            sample = self.sample_plms if sampler == 'plms' else self.sample_dpm
+            side = torch.cuda.Stream(device=self.device)
+            keep = self.use_hip_graph
+            self.use_hip_graph = False          # inside a capture the graphs run their launch lists
+            try:
+                z = sample(s_ctx, s_x, steps, guidance)                       # warm-up: kernel attributes, time embeddings, tuning
+                self.decode(z, mode=mode)
+                torch.cuda.synchronize(self.device)
+                g_s = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_s, capture_error_mode='thread_local'):
+                    z_s = sample(s_ctx, s_x, steps, guidance)
+                z_in = torch.empty_like(z_s)
+                g_d = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_d, capture_error_mode='thread_local'):
+                    out = self.decode(z_in, mode=mode)
+            finally:
+                self.use_hip_graph = keep
+            cache[key] = dict(g_s=g_s, g_d=g_d, s_ctx=s_ctx, s_x=s_x, z_s=z_s, z_in=z_in, out=out, side=side,
+                              copied=None, decoded=None)
+        c = cache[key]
+        main = torch.cuda.current_stream(self.device)
+        if c['copied'] is not None:
+            main.wait_event(c['copied'])        # the previous latent has left z_s
+        c['s_ctx'].copy_(ctx2); c['s_x'].copy_(x_T)
+        c['g_s'].replay()
+        sampled = torch.cuda.Event(); sampled.record(main)
+        with torch.cuda.stream(c['side']):
+            c['side'].wait_event(sampled)
+            c['z_in'].copy_(c['z_s'])
+            c['copied'] = torch.cuda.Event(); c['copied'].record(c['side'])
+            c['g_d'].replay()
+            c['decoded'] = torch.cuda.Event(); c['decoded'].record(c['side'])
+        return c['out'], c['decoded']
+
 
 def broadcast_conditioning(ctx2, src=0):
     """the one collective of the path: CLIP output [2,77,768] fp16 (236,544 B) from rank `src` to every rank over RCCL"""

@@ -104,6 +104,22 @@ def test_pipeline_is_deterministic_and_sharding_invariant(rig):
     assert torch.equal(d, pipe.generate(ctx2, x2, steps=4, guidance=7.5, sampler='plms')) and not torch.equal(d, a)
     e = pipe.generate_graphed(ctx2, x, steps=3, guidance=5.0, sampler='dpm').clone()
     assert torch.equal(e, pipe.generate(ctx2, x, steps=3, guidance=5.0, sampler='dpm'))
+    # throughput form: sampling graph on the current stream, decode graph on a side stream under the NEXT image's sampling --
+    # three images back to back, each identical to the serial result (the latent hand-off and the output buffer are the
+    # only shared state: an image is read after ITS event and before the next decode starts)
+    outs = []
+    for xi in (x, x2, x):
+        img, ev = pipe.generate_pipelined(ctx2, xi, steps=4, guidance=7.5, sampler='plms')
+        ev.synchronize()
+        outs.append(img.clone())
+    assert torch.equal(outs[0], a) and torch.equal(outs[1], d) and torch.equal(outs[2], a)
+    # ... and without waiting in between (the stream order alone must keep image i's latent intact until its decode has it)
+    evs = []
+    for xi in (x, x2):
+        img, ev = pipe.generate_pipelined(ctx2, xi, steps=4, guidance=7.5, sampler='plms')
+        evs.append(ev)
+    evs[-1].synchronize()
+    assert torch.equal(img, d)
 
 
 def test_config4_dpm_50_steps_two_images_per_gpu(rig, oracle_lib):
