@@ -128,6 +128,9 @@ SDOD_API int sdod_gemm_time_cold(const sdod_gemm_desc* d, void* stream, int iter
 SDOD_API size_t sdod_group_norm_workspace_bytes(int n, int groups);
 /* 1 = the single-launch kernel (whole image x channel set in LDS) handles this shape, 2 = statistics + apply launches */
 SDOD_API int sdod_group_norm_launches(int hw, int c, int groups, int dtype);
+/* which kernel the call below launches for this shape: 0 = one-launch grid-barrier kernel (maps >= 5 MB), 1 = one launch, a
+ * workgroup per (image, group), 2 = one launch, small-map LDS kernel, 3 = statistics + apply launches; -1 = bad shape */
+SDOD_API int sdod_group_norm_path(int n, int hw, int c0, int c1, int groups, int dtype);
 SDOD_API int sdod_group_norm_nhwc(const void* x, const void* x2, void* y, const float* weight, const float* bias,
                                   int n, int hw, int c0, int c1, int groups, float eps, int silu, int dtype,
                                   void* workspace, void* stream);
@@ -228,6 +231,10 @@ SDOD_API int sdod_image_to_u8(const void* img, uint8_t* out, size_t count, float
 
 SDOD_API const char* sdod_hip_last_error(void);
 SDOD_API int sdod_hip_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int arch_len);
+
+/* touch every 128-byte line of [ptr, ptr + bytes) once (a few workgroups on `stream`): the engine pulls the weights of the
+ * deep, weight-heavy GEMMs towards the Infinity Cache a few launches ahead of their consumer (engine.hip: Graph::run_ops) */
+SDOD_API int sdod_l2_prefetch(const void* ptr, size_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

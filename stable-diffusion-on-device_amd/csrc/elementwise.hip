@@ -509,3 +509,31 @@ extern "C" int sdod_image_to_u8(const void* img, uint8_t* out, size_t count, flo
     return 0;
     SDOD_CATCH
 }
+
+// ---- pull a buffer towards the caches: every 128-byte line touched once (Graph::run_ops: weight prefetch on a side stream)
+namespace {
+__global__ __launch_bounds__(256) void l2_prefetch_kernel(const unsigned* __restrict__ p, size_t lines, unsigned* sink) {
+    unsigned acc = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < lines; i += stride) acc += p[i * 32];
+    if (acc == 0x9e3779b9u) *sink = acc; // (keeps the loads alive; practically never true)
+}
+} // namespace
+
+extern "C" int sdod_l2_prefetch(const void* ptr, size_t bytes, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(ptr != nullptr && ((uintptr_t)ptr & 3) == 0, "null / unaligned pointer");
+    const size_t lines = bytes / 128;
+    if (lines == 0) return 0;
+    static unsigned* sink[64] = {};
+    int dev = 0;
+    SDOD_HIP_CHECK(hipGetDevice(&dev));
+    SDOD_REQUIRE(dev >= 0 && dev < 64, "device index");
+    if (!sink[dev]) SDOD_HIP_CHECK(hipMalloc((void**)&sink[dev], 256));
+    // few workgroups on purpose: the point is bytes in flight on an otherwise idle HBM, not CUs taken from the main chain
+    const int blocks = (int)std::min<size_t>(48, (lines + 255) / 256);
+    SDOD_LAUNCH(l2_prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned*)ptr, lines, sink[dev]);
+    SDOD_HIP_CHECK(hipGetLastError());
+    return 0;
+    SDOD_CATCH
+}

@@ -132,6 +132,8 @@ private:
         double flops = 0;    // algorithmic FLOPs of this launch (2*M*N*K, 4*B*H*Lq*Lk*D)
         double bytes = 0;    // algorithmic HBM bytes of this launch (operands read once + result written once)
         std::string detail;  // shape, for the per-layer profile table (tools/unet_profile.py)
+        const void* pf_ptr = nullptr; // weight-heavy GEMM: its weight matrix, pulled towards the Infinity Cache ahead of the launch
+        size_t pf_bytes = 0;
     };
     std::vector<Op> ops_;
     std::vector<Op> static_ops_; // depend only on static inputs; run by execute() unless skip_static
@@ -140,6 +142,9 @@ private:
     hipGraphExec_t graph_exec_ = nullptr;
     hipGraph_t hip_graph_ = nullptr;
     hipStream_t capture_stream_ = nullptr;
+    hipStream_t side_stream_ = nullptr;     // weight prefetch branch (run_ops)
+    std::vector<hipEvent_t> pf_events_;     // fork / join events of that branch
+    void run_ops(hipStream_t st);
     int eager_runs_ = 0;
     int tune_hits_ = 0, tune_misses_ = 0;
 

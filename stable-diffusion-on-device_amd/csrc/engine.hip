@@ -54,6 +54,8 @@ Graph::Graph(int kind, const sdod_model_config& cfg, int batch) : kind_(kind), c
 Graph::~Graph() {
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
     if (capture_stream_) (void)hipStreamDestroy(capture_stream_);
+    if (side_stream_) (void)hipStreamDestroy(side_stream_);
+    for (hipEvent_t e : pf_events_) (void)hipEventDestroy(e);
     if (hip_graph_) (void)hipGraphDestroy(hip_graph_);
     for (auto& s : inputs_) (void)hipFree(s.ptr);
     for (auto& s : outputs_) (void)hipFree(s.ptr);
@@ -479,6 +481,7 @@ IoSlot Graph::io(bool output, int index) const {
 // launch meets inside a replay: the UNet's weights are 1.7 GB, the Infinity Cache 256 MiB.  SDOD_AUTOTUNE=0 disables the
 // tuner (gemm.hip's static heuristic decides), SDOD_AUTOTUNE=hot ranks with back-to-back launches instead.
 namespace {
+constexpr size_t kPrefetchMinBytes = (size_t)12 << 20; // weight matrices at least this big are prefetched (Graph::run_ops)
 const int kCandidates[] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, // (25, 26 spill in their epilogue only; the tuner decides)
                            37, 38, 39, 40, 41, 42, 43, 44, 45}; // halo-patch convolution tiles: rejected by every other descriptor
 
@@ -660,6 +663,10 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
         d2.phase = 2;
         const double part = (double)splits * d.M * d.N * 4;
         sink().push_back(Op{[d1](hipStream_t st) { check_rc(sdod_gemm_f16(&d1, st)); }, label, fl, by + part, detail});
+        if ((size_t)d.N * d.ldw * (d.wq ? 1 : 2) >= kPrefetchMinBytes) {
+            sink().back().pf_ptr = d.w;
+            sink().back().pf_bytes = (size_t)d.N * d.ldw * (d.wq ? 1 : 2);
+        }
         // phase 2 is deferred: a GroupNorm that consumes d.out next folds it into its load (group_norm()), anything else
         // emits it as the stand-alone reduce launch
         pending_.active = true;
@@ -675,6 +682,10 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
         return;
     }
     sink().push_back(Op{[d](hipStream_t st) { check_rc(sdod_gemm_f16(&d, st)); }, label, fl, by, detail});
+    if ((size_t)d.N * d.ldw * (d.wq ? 1 : 2) >= kPrefetchMinBytes) {
+        sink().back().pf_ptr = d.w;
+        sink().back().pf_bytes = (size_t)d.N * d.ldw * (d.wq ? 1 : 2);
+    }
 }
 
 void Graph::linear_raw(const f16* x, int rows, int K, const f16* w, int ldw, int N, f16* out, const GemmOpt& o) {
@@ -797,7 +808,14 @@ Act Graph::group_norm(const Act& x, const Act* x2, int gw, int gb, float eps, bo
             void* ws = gn_ws_;
             ops_.push_back(Op{[=](hipStream_t st) {
                 check_rc(sdod_group_norm_nhwc(xp, x2p, yp, wp, bp, n, hw, c0, c1, 32, eps, si, SDOD_F16, ws, st));
-            }, sdod_group_norm_launches(hw, c0 + c1, 32, SDOD_F16) == 1 ? "gn_group" : "gn_stats_apply", 0, 2.0 * n * hw * (c0 + c1) * 2, shape});
+            }, [&] { // one label per kernel symbol, so that per-label timings line up with a profiler's per-symbol numbers
+                switch (sdod_group_norm_path(n, hw, c0, c1, 32, SDOD_F16)) {
+                case 0: return "gn_grid";
+                case 1: return "gn_group";
+                case 2: return "gn_small";
+                default: return "gn_stats_apply";
+                }
+            }(), 0, 2.0 * n * hw * (c0 + c1) * 2, shape});
         }
     }
     drain_parked();
@@ -882,13 +900,61 @@ void Graph::finalize() {
     finalized_ = true;
 }
 
+// ---- weight prefetch.  Inside a replay every weight matrix comes from HBM (1.7 GB of weights sweep the 256 MiB Infinity Cache
+// many times per evaluation) and the deep, weight-heavy GEMMs -- 30-60 MB of weights for a few microseconds of arithmetic on
+// a 16x16 or 8x8 map -- are bound by the bytes they can keep in flight: timed with their weights cache-resident they run
+// 25-35 % faster (profiles/r02_deep_conv_hot_cold.txt).  HBM itself is ~95 % idle over the evaluation, so a tiny kernel on a
+// side stream touches every 128-byte line of such a matrix a few launches ahead of its consumer (a parallel branch of the
+// captured graph: fork by event, one join behind the last launch).
+// MEASURED: the branch costs far more than it brings -- 8.04 vs 9.56 images/s on one box (bench.py, SDOD_PREFETCH=1 vs unset):
+// like the decode / sampling overlap, anything running next to the latency-bound main chain slows it down.  OFF unless
+// SDOD_PREFETCH=1; kept as a documented experiment.
+namespace {
+constexpr int kPrefetchLookahead = 3;
+bool prefetch_enabled() {
+    static const bool on = [] { const char* e = std::getenv("SDOD_PREFETCH"); return e && e[0] == '1'; }();
+    return on;
+}
+} // namespace
+
+void Graph::run_ops(hipStream_t st) {
+    const bool pf = prefetch_enabled() && g_launch_timer == nullptr;
+    size_t ev = 0;
+    bool forked = false;
+    auto next_event = [&]() {
+        if (ev == pf_events_.size()) {
+            hipEvent_t e = nullptr;
+            SDOD_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            pf_events_.push_back(e);
+        }
+        return pf_events_[ev++];
+    };
+    for (size_t i = 0; i < ops_.size(); ++i) {
+        const size_t j = i + kPrefetchLookahead;
+        if (pf && j < ops_.size() && ops_[j].pf_bytes) {
+            if (!side_stream_) SDOD_HIP_CHECK(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
+            hipEvent_t fork = next_event();
+            SDOD_HIP_CHECK(hipEventRecord(fork, st));
+            SDOD_HIP_CHECK(hipStreamWaitEvent(side_stream_, fork, 0));
+            check_rc(sdod_l2_prefetch(ops_[j].pf_ptr, ops_[j].pf_bytes, side_stream_));
+            forked = true;
+        }
+        ops_[i].fn(st);
+    }
+    if (forked) { // the branch rejoins behind the last launch (a capture must end with every forked stream joined)
+        hipEvent_t join = next_event();
+        SDOD_HIP_CHECK(hipEventRecord(join, side_stream_));
+        SDOD_HIP_CHECK(hipStreamWaitEvent(st, join, 0));
+    }
+}
+
 void Graph::execute(hipStream_t st, bool use_hip_graph, bool skip_static) {
     SDOD_REQUIRE(finalized_, "graph not finalized");
     if (!skip_static || eager_runs_ == 0)
         for (auto& op : static_ops_) op.fn(st);
     if (!use_hip_graph || eager_runs_ == 0) {
         // the first run is always eager: it sets kernel attributes (dynamic LDS sizes), which must not happen in capture
-        for (auto& op : ops_) op.fn(st);
+        run_ops(st);
         ++eager_runs_;
         return;
     }
@@ -899,7 +965,7 @@ void Graph::execute(hipStream_t st, bool use_hip_graph, bool skip_static) {
         SDOD_HIP_CHECK(hipStreamSynchronize(st));
         SDOD_HIP_CHECK(hipStreamBeginCapture(capture_stream_, hipStreamCaptureModeThreadLocal));
         try {
-            for (auto& op : ops_) op.fn(capture_stream_);
+            run_ops(capture_stream_);
         } catch (...) {
             hipGraph_t g = nullptr;
             (void)hipStreamEndCapture(capture_stream_, &g);

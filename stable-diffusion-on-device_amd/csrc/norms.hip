@@ -1261,6 +1261,17 @@ extern "C" int sdod_group_norm_launches(int hw, int c, int groups, int dtype) {
     return gn_small_fits(hw, c, c / groups, dtype == SDOD_F16 ? 2 : 4) ? 1 : 2; // (+1 collapse launch on very large maps)
 }
 
+// which kernel sdod_group_norm_nhwc launches for this shape: 0 = the one-launch grid-barrier kernel (big maps), 1 = the (image,
+// group) one-launch kernel, 2 = the small-map LDS kernel, 3 = statistics + apply (two or three launches)
+extern "C" int sdod_group_norm_path(int n, int hw, int c0, int c1, int groups, int dtype) {
+    const int c = c0 + c1;
+    if (n <= 0 || hw <= 0 || c <= 0 || groups <= 0 || c % groups) return -1;
+    if (dtype == SDOD_F16 && groups <= 32 && gn2_fits(c0, c1, groups) && gn_path_override() == 2) return 3;
+    if (dtype == SDOD_F16 && gn_path_override() == 0 && gn_grid_plan(n, hw, c0, c1, groups, nullptr)) return 0;
+    if (dtype == SDOD_F16 && c0 % 8 == 0 && c1 % 8 == 0 && gn_group_plan(hw, c0, c1, c / groups, false).v && gn_path_override() != 2) return 1;
+    return gn_small_fits(hw, c, c / groups, dtype == SDOD_F16 ? 2 : 4) ? 2 : 3;
+}
+
 extern "C" int sdod_group_norm_reduce_ok(int hw, int c0, int c1, int groups) {
     if (hw <= 0 || c0 <= 0 || c1 < 0 || groups <= 0 || (c0 + c1) % groups || c0 % 8 || c1 % 8) return 0;
     return gn_group_plan(hw, c0, c1, (c0 + c1) / groups, true).v ? 1 : 0;
