@@ -99,9 +99,19 @@ typedef struct sdod_gemm_desc {
     int wq;
     const void* w_scale;           /* fp32 [N] */
     const void* w_off;             /* fp32 [N] */
+    /* --- split-K without a reduce launch (halo-patch convolution tiles): a buffer of >= sdod_gemm_fixup_counters() 32-bit
+     * words, ZEROED ONCE by its owner, used by one launch at a time (one per stream of concurrent callers) and left zeroed by
+     * every launch.  With it, a phase-0 call of a split-K plan on such a tile is ONE launch: every K slice publishes its fp32
+     * tile, the slice that arrives last at the tile's counter reduces (in slice order: bit-identical to the reduce kernel)
+     * and runs the fused epilogue.  NULL: partial slabs + splitk_reduce_kernel as before. */
+    void* fix_counters;
 } sdod_gemm_desc;
 
 SDOD_API int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream);
+/* 1 when the call above reduces its split-K slices inside the GEMM launch (see fix_counters), else 0 */
+SDOD_API int sdod_gemm_fixup(const sdod_gemm_desc* d);
+/* counter words a fix_counters buffer must hold for any descriptor (one per output tile; 64 Ki covers M*N up to 2^28 at 64x64) */
+SDOD_API size_t sdod_gemm_fixup_counters(void);
 /* picks split_k / tile as the auto heuristic would; returns required workspace bytes */
 SDOD_API size_t sdod_gemm_workspace_bytes(const sdod_gemm_desc* d);
 /* which tile configuration (1: 128x128, 2: 128x64, 3: 64x64, 4: 256x16, 5: 64x128) and split-K factor the call would use */

@@ -142,6 +142,7 @@ private:
     hipGraphExec_t graph_exec_ = nullptr;
     hipGraph_t hip_graph_ = nullptr;
     hipStream_t capture_stream_ = nullptr;
+    unsigned* fix_counters_ = nullptr;      // tile counters of the in-kernel split-K reduce (gemm.hip), zeroed once
     hipStream_t side_stream_ = nullptr;     // weight prefetch branch (run_ops)
     std::vector<hipEvent_t> pf_events_;     // fork / join events of that branch
     void run_ops(hipStream_t st);

@@ -55,6 +55,7 @@ Graph::~Graph() {
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
     if (capture_stream_) (void)hipStreamDestroy(capture_stream_);
     if (side_stream_) (void)hipStreamDestroy(side_stream_);
+    (void)hipFree(fix_counters_);
     for (hipEvent_t e : pf_events_) (void)hipEventDestroy(e);
     if (hip_graph_) (void)hipGraphDestroy(hip_graph_);
     for (auto& s : inputs_) (void)hipFree(s.ptr);
@@ -594,6 +595,7 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
     if (tune) {
         d.workspace = ws_;
         d.workspace_bytes = ws_bytes_;
+        d.fix_counters = std::getenv("SDOD_GEMM_FIXUP") && std::getenv("SDOD_GEMM_FIXUP")[0] == '1' ? fix_counters_ : nullptr;
         const ShapeKey key = key_of(d);
         auto it = tune_cache().find(key);
         if (it != tune_cache().end()) ++tune_hits_;
@@ -646,6 +648,7 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
     flops_ += fl;
     d.workspace = ws_;
     d.workspace_bytes = ws_bytes_;
+    d.fix_counters = fix_counters_;
     int tile = 0, splits = 1;
     (void)sdod_gemm_plan(&d, &tile, &splits);
     std::string label = "gemm_t" + std::to_string(tile); // one label per kernel symbol (tile table in gemm.hip); "xS" in the detail = split-K
@@ -656,6 +659,20 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
     std::string detail = (d.a_mode == SDOD_A_ROWS ? std::string("rows") : "conv" + std::to_string(d.ksize) + (d.upsample ? "u" : "") +
                                                                           (d.stride == 2 ? "s2" : "") + (d.c1 ? "+cat" : "")) +
                          " M" + std::to_string(d.M) + " N" + std::to_string(d.N) + " K" + std::to_string(d.K) + " x" + std::to_string(splits);
+    // In-kernel split-K reduce (gemm.hip: the last K slice to arrive at the tile's counter reduces; sdod_gemm_desc::fix_counters):
+    // built, bit-identical to the reduce kernel, 31 launches fewer per evaluation -- and SLOWER: the evaluation's convolutions +
+    // reduces take 1499 us against 1385 us (8-byte agent atomics: 1655 us): write-through partial stores, a fabric round trip
+    // for the counter and a serial tail of (slices - 1) tile reads on one workgroup cost more than a reduce launch that runs on
+    // the whole chip out of L2.  OFF unless SDOD_GEMM_FIXUP=1.
+    static const bool fixup_on = [] { const char* e = std::getenv("SDOD_GEMM_FIXUP"); return e && e[0] == '1'; }();
+    if (!fixup_on) d.fix_counters = nullptr;
+    static const bool fuse_reduce_gn = [] { const char* e = std::getenv("SDOD_GN_REDUCE"); return e && e[0] == '1'; }();
+    if (splits > 1 && !fuse_reduce_gn && sdod_gemm_fixup(&d)) {
+        // the K slices are reduced inside the GEMM launch: ONE entry
+        const double part = (double)splits * d.M * d.N * 4;
+        sink().push_back(Op{[d](hipStream_t st) { check_rc(sdod_gemm_f16(&d, st)); }, label, fl, by + part, detail});
+        return;
+    }
     if (splits > 1) {
         // two launch-list entries, one per kernel, so that per-launch timings line up with rocprofv3's per-symbol numbers
         sdod_gemm_desc d1 = d, d2 = d;
@@ -881,6 +898,8 @@ void Graph::finalize() {
     SDOD_HIP_CHECK(hipMalloc((void**)&ws_, ws_bytes_));
     SDOD_HIP_CHECK(hipMalloc((void**)&gn_ws_, gn_ws_bytes_));
     SDOD_HIP_CHECK(hipMemset(gn_ws_, 0, gn_ws_bytes_)); // the one-launch GroupNorm keeps its grid-barrier words in here: zero once
+    SDOD_HIP_CHECK(hipMalloc((void**)&fix_counters_, sdod_gemm_fixup_counters() * sizeof(unsigned)));
+    SDOD_HIP_CHECK(hipMemset(fix_counters_, 0, sdod_gemm_fixup_counters() * sizeof(unsigned)));
     if (kind_ == SDOD_GRAPH_UNET && kv_total_ > 0)
         SDOD_HIP_CHECK(hipMalloc((void**)&kv_all_, (size_t)batch_ * cfg_.context_len * kv_total_ * sizeof(f16)));
     mode_ = REAL;

@@ -67,6 +67,8 @@ struct GemmP {
     int wq;
     const float* w_scale;
     const float* w_off;
+    int fixup;               // split-K without a reduce launch: the last slice to arrive at a tile's counter reduces (conv_halo_kernel)
+    unsigned* fix_counters;  // [tiles_m * tiles_n], zero when idle (in the caller's zeroed workspace, behind the partial slabs)
     int lean; // plain row-major operands whose byte offsets fit 32 bits: the loaders take the short issue path
     // halo-patch convolution (conv_halo_kernel, tiles 37..): geometry of one workgroup's output tile and of the input patch
     // it keeps in LDS, all host-computed (halo_geometry)
@@ -1277,10 +1279,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
     }
 
     f16* sC = smem;
-    auto store_phase = [&]() {
+    auto store_phase = [&](int nthr) { // nthr = threads of the workgroup still alive (512; 256 behind an in-kernel split-K fixup)
         constexpr int CPR = BN / 8; // 16-byte chunks per output tile row
         const bool vec_ok = (p.N % 8 == 0) && (p.ldo % 8 == 0) && (p.residual == nullptr || p.ldr % 8 == 0);
-        for (int idx = tid; idx < BM * CPR; idx += NT) {
+        for (int idx = tid; idx < BM * CPR; idx += nthr) {
             const int row = idx / CPR;
             const int ch = idx - row * CPR;
             const int m = m0 + row, n = n0 + ch * 8;
@@ -1456,7 +1458,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
         if (p.splits > 1) return;
         __syncthreads(); // the consumers have staged the output tile
         STAMP(3);
-        store_phase();
+        store_phase(NT);
 #ifdef SDOD_GEMM_STAMP
         wait_vmcnt<0>();
         STAMP(4);
@@ -1623,7 +1625,83 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
     __syncthreads(); // all fragment reads done before the epilogue tile overwrites the ring
     STAMP(2);
 
-    if (p.splits > 1) {
+    int n_store = NT; // threads that take part in the store phase
+    if (p.splits > 1 && p.fixup) {
+        // ---- split-K WITHOUT a reduce launch: every slice publishes its fp32 tile write-through, the slice that arrives LAST at
+        // the tile's counter adds the others to its own accumulators (in slice order, its own in its place: the sum the
+        // reduce kernel forms, bit for bit) and runs the fused epilogue.  Cross-XCD hand-off as in gn_grid_kernel: 8-byte
+        // agent-scope atomics (= sc1 stores / loads) both sides, every storing wave waits for its stores, one lane signals;
+        // the kernel's N is a multiple of 4 (host check).  Only the four consumer waves are still alive here (the loaders
+        // returned behind the barrier above), so the barriers below are theirs.
+        // 16-byte sc1 accesses by inline asm (the 8-byte agent-scope atomics the compiler offers cost 2.7x per byte on the store
+        // side: one fabric write each); the loads are waited for by hand below
+        auto pub = [&](float* dst, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory"); };
+        auto sub = [&](const float* src) {
+            f32x4 v;
+            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(src) : "memory");
+            return v;
+        };
+        const size_t slab_floats = (size_t)p.M * p.N;
+        float* mine = p.partial + (size_t)split * slab_floats;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + e_m;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + e_n;
+                if (n < p.N) pub(mine + (size_t)m * p.N + n, acc[i][j]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem_raw); // (the ring is dead: every fragment read is done)
+        if (tid == 0) {
+            unsigned* cnt = p.fix_counters + (size_t)tile_m * p.tiles_n + tile_n;
+            const unsigned prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = prev + 1u == (unsigned)p.splits;
+            if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-armed for the next launch
+            *flag = last ? 1 : 0;
+        }
+        __syncthreads();
+        const bool last = *flag != 0;
+        __syncthreads(); // (the flag word is overwritten by the output tile below)
+        if (!last) return;
+        f32x4 sum[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) sum[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s2 = 0; s2 < p.splits; ++s2) {
+            const float* slab = p.partial + (size_t)s2 * slab_floats;
+            f32x4 t[TM][TN];
+            if (s2 != split) { // the whole tile of that slice in flight at once, then one wait
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int m = min(m0 + wm * WTM + i * 16 + e_m, p.M - 1);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int n = min(n0 + wn * WTN + j * 16 + e_n, p.N - 4);
+                        t[i][j] = sub(slab + (size_t)m * p.N + n); // (clamped rows / columns are never stored)
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(t[i][j])); // uses stay behind the wait
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) sum[i][j] += s2 != split ? t[i][j] : acc[i][j];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = sum[i][j];
+        n_store = 256;
+    } else if (p.splits > 1) {
         float* slab = p.partial + (size_t)split * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -1706,7 +1784,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
     }
     __syncthreads();
     STAMP(3);
-    store_phase();
+    store_phase(n_store);
 #ifdef SDOD_GEMM_STAMP
     wait_vmcnt<0>();
     STAMP(4);
@@ -1989,6 +2067,22 @@ Plan make_plan(const sdod_gemm_desc* d) {
 
 } // namespace
 
+namespace {
+constexpr size_t kFixupCounters = (size_t)64 << 10;
+bool fixup_applies(const sdod_gemm_desc* d, const Plan& pl) {
+    if (!d->fix_counters || d->phase != 0 || pl.splits <= 1 || pl.tile < kFirstHaloTile || d->N % 4 != 0) return false;
+    const size_t tiles = (size_t)((d->M + kTiles[pl.tile].bm - 1) / kTiles[pl.tile].bm) * ((d->N + kTiles[pl.tile].bn - 1) / kTiles[pl.tile].bn);
+    return tiles <= kFixupCounters && halo_geometry(d, pl.tile, nullptr, nullptr);
+}
+} // namespace
+
+extern "C" size_t sdod_gemm_fixup_counters(void) { return kFixupCounters; }
+
+extern "C" int sdod_gemm_fixup(const sdod_gemm_desc* d) {
+    if (!d || d->K <= 0 || d->K % BK) return 0;
+    return fixup_applies(d, make_plan(d)) ? 1 : 0;
+}
+
 extern "C" size_t sdod_gemm_workspace_bytes(const sdod_gemm_desc* d) {
     if (!d || d->K <= 0 || d->K % BK) return 0;
     const Plan pl = make_plan(d);
@@ -2158,6 +2252,10 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     if (pl.tile >= kFirstHaloTile) {
         SDOD_REQUIRE(halo_geometry(d, pl.tile, &p, &halo_smem), "this halo-patch tile does not take the convolution (3x3, stride 1, tile rows must divide the image)");
         p.h_main_splits = pl.main_splits;
+        if (fixup_applies(d, pl)) {
+            p.fixup = 1;
+            p.fix_counters = (unsigned*)d->fix_counters;
+        }
     }
     if (pl.splits > 1) {
         SDOD_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= (size_t)pl.splits * d->M * d->N * sizeof(float),
@@ -2236,7 +2334,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     default: e = launch_glds<128, 128, 2, 2, 2, true, false, 2>(p, grid, st); break;
     }
     SDOD_HIP_CHECK(e);
-    if (pl.splits > 1 && d->phase != 1) {
+    if (pl.splits > 1 && d->phase != 1 && !p.fixup) {
         const size_t total = (size_t)d->M * ((d->N + 3) / 4);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;

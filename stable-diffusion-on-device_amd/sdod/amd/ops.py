@@ -47,7 +47,7 @@ def workspace(nbytes, device, tag='default'):
 
 def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=None, alpha=1.0, out=None,
          conv=None, a2=None, bias_on_m=False, split_k=0, tile=0, time_iters=0, geglu=False, tail=None, bias2=None,
-         ln_s=None, ln_eps=1e-5, cold_scratch=None, phase=0, return_desc=False, w_scale=None, w_off=None):
+         ln_s=None, ln_eps=1e-5, cold_scratch=None, phase=0, return_desc=False, w_scale=None, w_off=None, fixup=False):
     """out = act(alpha * A @ W^T + bias + row_bias) + residual.
 
     a: fp16 [M, K] (rows mode) or NHWC [N, H, W, C0] with conv=dict(stride=1|2, upsample=bool) (3x3 pad 1);
@@ -123,6 +123,8 @@ def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=N
     if need:
         ws = workspace(need, a.device, 'gemm')
         d.workspace = _p(ws); d.workspace_bytes = ws.numel() * 4
+        if fixup:   # split-K reduced inside the GEMM launch where the tile supports it (zeroed counters, see include/sdod_hip.h)
+            d.fix_counters = _p(workspace(lib.sdod_gemm_fixup_counters() * 4, a.device, 'gemm_fixup'))
     if time_iters:
         ms = ctypes.c_float()
         if cold_scratch is not None:   # cold weights, warm activations: what the launch meets inside a graph replay

@@ -304,6 +304,12 @@ def test_conv3x3_halo_patch_tiles(n, h, w, cin, cout, tile, split):
     d = dev()
     out = _halo_gemm(ops, x.to(d), wt.to(d), bias.to(d), conv=dict(stride=1), tile=tile, split_k=split)
     check(out, ref, name=f'halo conv {n}x{h}x{w} {cin}->{cout} tile{tile} split{split}')
+    # opt-in: a split-K plan reduced INSIDE the GEMM launch (last K slice to arrive at the tile's counter reduces; fix_counters in
+    # include/sdod_hip.h) -- the same sum in the same order as splitk_reduce_kernel, so the same bits, also on a second launch
+    # (the counters must be back at zero)
+    for _ in range(2):
+        one_launch = ops.gemm(x.to(d), wt.to(d), bias.to(d), conv=dict(stride=1), tile=tile, split_k=split, fixup=True)
+        assert torch.equal(one_launch, out), 'in-kernel split-K reduce differs from splitk_reduce_kernel'
 
 
 @pytest.mark.parametrize('split', [1, 2])
@@ -333,6 +339,8 @@ def test_conv3x3_halo_concat_rowbias_residual_tail(tile, split):
     wcat = torch.cat([w3, w1], 1).contiguous()
     out = _halo_gemm(ops, hmid.to(d), wcat.to(d), b3.to(d), conv=dict(stride=1), tail=(x0.to(d), x1.to(d)), bias2=b1.to(d), tile=tile, split_k=split)
     check(out, ref, name=f'halo conv + skip tail tile{tile} split{split}')
+    one_launch = ops.gemm(hmid.to(d), wcat.to(d), b3.to(d), conv=dict(stride=1), tail=(x0.to(d), x1.to(d)), bias2=b1.to(d), tile=tile, split_k=split, fixup=True)
+    assert torch.equal(one_launch, out)
 
 
 @pytest.mark.parametrize('split', [0, 2])
