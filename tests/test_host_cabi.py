@@ -119,3 +119,73 @@ def test_weight_container_roundtrip(tmp_path):
     back = Wt.load(str(p))
     assert list(back) == list(sd)
     assert all(torch.equal(sd[k], back[k]) and sd[k].dtype == back[k].dtype for k in sd)
+
+
+def _conv_desc(n, h, w, c0, cout, c1=0, ups=False, stride=1, tail=0, tile=0, split=0):
+    """a sdod_gemm_desc for a 3x3 convolution with fake (non-null, never dereferenced) pointers: planning calls only"""
+    from sdod.amd._lib import GemmDesc
+    d = GemmDesc()
+    d.a = d.w = d.out = 0x1000
+    d.a2 = 0x1000 if c1 else None
+    d.a_mode = 1; d.ksize = 3; d.stride = stride; d.upsample = 1 if ups else 0
+    d.n_img, d.h_in, d.w_in, d.c0, d.c1 = n, h, w, c0, c1
+    ho, wo = (h << ups) // stride, (w << ups) // stride
+    d.M, d.N, d.K = n * ho * wo, cout, 9 * (c0 + c1) + tail
+    d.ldw, d.ldo = d.K, cout
+    if tail:
+        d.k_tail = 9 * (c0 + c1); d.t0 = 0x1000; d.tc0 = tail
+    d.tile, d.split_k = tile, split
+    return d
+
+
+def test_halo_patch_tile_planning_without_a_gpu():
+    """host side of conv_halo_kernel (gemm.hip: halo_geometry / make_plan): K slices are whole 64-channel chunks, a fused 1x1
+    tail is one more slice, the in-kernel reduce needs counters, and geometries the tile cannot hold fall back to the generic
+    plan (the launch would refuse them) -- sdod_gemm_plan / sdod_gemm_fixup / sdod_gemm_workspace_bytes only, no launches"""
+    import ctypes
+    from sdod.amd import _lib
+    lib = _lib.hip()
+    t, s = ctypes.c_int(), ctypes.c_int()
+
+    def plan(d):
+        assert lib.sdod_gemm_plan(ctypes.byref(d), ctypes.byref(t), ctypes.byref(s)) == 0
+        return t.value, s.value
+
+    # 64x64 x 320 -> 320 on the 128x80 tile (38): 5 chunks; asking for 2 slices gives ceil(5/3) = 2, for 8 at most 5
+    assert plan(_conv_desc(2, 64, 64, 320, 320, tile=38, split=2)) == (38, 2)
+    assert plan(_conv_desc(2, 64, 64, 320, 320, tile=38, split=8)) == (38, 5)
+    assert plan(_conv_desc(2, 64, 64, 320, 320, tile=38, split=1)) == (38, 1)
+    # the fused 1x1 skip (tail) is ONE extra slice
+    assert plan(_conv_desc(2, 16, 16, 1280, 1280, tail=2560, tile=41, split=3)) == (41, 4)
+    # workspace = slices x M x N fp32
+    d = _conv_desc(2, 16, 16, 1280, 1280, tile=41, split=3)
+    assert lib.sdod_gemm_workspace_bytes(ctypes.byref(d)) == 3 * 512 * 1280 * 4
+    # in-kernel reduce: only with counters, a split plan, phase 0
+    assert lib.sdod_gemm_fixup(ctypes.byref(d)) == 0
+    d.fix_counters = 0x2000
+    assert lib.sdod_gemm_fixup(ctypes.byref(d)) == 1
+    d.phase = 1
+    assert lib.sdod_gemm_fixup(ctypes.byref(d)) == 0
+    d1 = _conv_desc(2, 64, 64, 320, 320, tile=38, split=1); d1.fix_counters = 0x2000
+    assert lib.sdod_gemm_fixup(ctypes.byref(d1)) == 0
+    assert lib.sdod_gemm_fixup_counters() >= 16384
+    # nearest-2x upsampling is taken (patch cut from the source), stride 2 is not: the generic plan answers instead
+    assert plan(_conv_desc(2, 32, 32, 640, 640, ups=True, tile=39, split=1)) == (39, 1)
+    tile, splits = plan(_conv_desc(2, 32, 32, 640, 640, stride=2, tile=39, split=3))
+    assert tile == 39 and splits == 3            # generic K split (90 slabs / 3), not chunk-granular
+    # tile metadata for profilers: SPEC column 2 marks conv_halo_kernel<BM, BN, WM, WN, STAGES>
+    info = (ctypes.c_int * 7)()
+    assert lib.sdod_gemm_tile_info(38, info) == 0 and list(info) == [128, 80, 4, 1, 4, 2, 1]
+    assert lib.sdod_gemm_num_tiles() >= 45
+
+
+def test_group_norm_path_selection_without_a_gpu():
+    """sdod_group_norm_path: which kernel a shape gets; without a device there is no CU count, so the grid-barrier kernel is
+    never chosen here (path 0 is covered by the GPU suite)"""
+    from sdod.amd import _lib
+    lib = _lib.hip()
+    assert lib.sdod_group_norm_path(2, 1024, 640, 0, 32, 0) == 1        # (image, group) one-launch kernel
+    assert lib.sdod_group_norm_path(2, 256, 1280, 640, 32, 0) == 1      # concat source
+    assert lib.sdod_group_norm_path(1, 100, 64, 0, 32, 1) in (2, 3)     # fp32: LDS / two-pass kernels
+    assert lib.sdod_group_norm_path(2, 64, 30, 0, 32, 0) == -1          # channels not divisible by groups
+    assert lib.sdod_group_norm_workspace_bytes(2, 32) >= (2 * 1024 * 32 * 2 + 2 * 32 * 3 + 32 * 26) * 4
