@@ -609,8 +609,15 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
-            const int n = min(n0 + (i * NL + lw) * 8 + lrow, p.N - 1);
-            b_off[i] = ((unsigned)n * (unsigned)p.ldw + (unsigned)lchunk * 8u) * 2u;
+            if (!WQ) {
+                const int n = min(n0 + (i * NL + lw) * 8 + lrow, p.N - 1);
+                b_off[i] = ((unsigned)n * (unsigned)p.ldw + (unsigned)lchunk * 8u) * 2u;
+            } else { // uint8 weights: 64-byte slab rows, lanes 0..31 cover the same 8 rows (see setup_rows)
+                const int r = (i * NL + lw) * 8 + ((lane & 31) >> 2);
+                const int n = min(n0 + r, p.N - 1);
+                const int lc = (lane & 3) ^ ((r >> 2) & 3);
+                b_off[i] = (unsigned)n * (unsigned)p.ldw + (unsigned)lc * 16u; // ldw in bytes
+            }
         }
     };
 
@@ -620,11 +627,12 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
         f16* sB = sA + BM * 64;
         if (lean) {
             const f16* ab = p.a0 + k0;
-            const f16* wb = p.w + k0;
+            const f16* wb = WQ ? reinterpret_cast<const f16*>(reinterpret_cast<const unsigned char*>(p.w) + k0) : p.w + k0;
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) lds_dma16_saddr(ab, a_off[i], sA + (i * NL + lw) * 8 * 64);
 #pragma unroll
-            for (int i = 0; i < B_LD; ++i) lds_dma16_saddr(wb, b_off[i], sB + (i * NL + lw) * 8 * 64);
+            for (int i = 0; i < B_LD; ++i)
+                if (!WQ || lane < 32) lds_dma16_saddr(wb, b_off[i], sB + (i * NL + lw) * 8 * 64);
             return;
         }
         if (p.k_tail && k0 >= p.k_tail) {
@@ -2241,7 +2249,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         p.c0 = d->K; p.c1 = 0; p.h_in = p.w_in = p.h_out = p.w_out = 1; p.stride = 1; p.ksize = 1;
         p.sa0 = d->lda; p.sa1 = 0;
     }
-    p.lean = (d->a_mode == SDOD_A_ROWS && !d->wq && !d->k_tail && (unsigned long long)d->M * d->lda * 2 < (1ull << 32) &&
+    p.lean = (d->a_mode == SDOD_A_ROWS && !d->k_tail && (unsigned long long)d->M * d->lda * 2 < (1ull << 32) &&
               (unsigned long long)d->N * d->ldw * 2 < (1ull << 32) && !lean_disabled()) ? 1 : 0;
     const Plan pl = make_plan(d);
     SDOD_REQUIRE(!(d->geglu && (pl.tile == 21 || pl.tile == 22 || pl.tile == 31 || pl.tile == 35)), "geglu needs a tile with an even number of 16-column blocks per wave");
