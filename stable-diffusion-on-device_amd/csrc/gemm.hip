@@ -390,16 +390,10 @@ constexpr int halo_rounds_between(int ti, int ahead, int nrmax, int rpt) {
     return n;
 }
 
-// 16-byte-per-lane LDS-DMA issued BEHIND THE COMPILER'S BACK.  The waitcnt pass models global_load_lds as a FLAT access that
-// may touch LDS: while one is pending (and it cannot see the hand-counted s_waitcnt vmcnt that retire them) it turns every
-// LDS wait of the wave into lgkmcnt(0) -- a wave that both fetches by DMA and software-pipelines its fragment reads
-// (conv_halo_kernel's consumers) would wait for the fragments it has just requested.  lds_dst must be wave-uniform.
-SDOD_DEVICE void lds_dma16_opaque(const void* g, f16* lds_dst) {
-    const unsigned a = (unsigned)(uintptr_t)(lds_void_ptr)lds_dst;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(a) : "memory", "m0");
-}
-
 // 16-byte-per-lane LDS-DMA in the SADDR form: address = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset.
+// (Inline asm also keeps the DMA out of the compiler's wait-count model, which treats global_load_lds as a FLAT access that may
+// touch LDS and, while one is pending, turns every LDS wait of the wave into lgkmcnt(0); the waits for these DMAs are the
+// hand-counted s_waitcnt vmcnt(N) of the loaders.)
 // Three instructions per DMA (m0, the hazard nop, the load) and no vector arithmetic; the compiler's own selection of the
 // builtin spends two 64-bit vector adds per DMA on the same address.  base and lds_dst must be wave-uniform.
 SDOD_DEVICE void lds_dma16_saddr(const void* base, unsigned off, f16* lds_dst) {
@@ -438,17 +432,8 @@ __device__ unsigned long long g_stamp[8 * 8192];
         const unsigned wg_ = blockIdx.x + gridDim.x * blockIdx.z;                                           \
         if (threadIdx.x == 0 && wg_ < 8192) g_stamp[wg_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime();     \
     } while (0)
-// ... and a shader-clock (s_memtime) timeline of ONE main-loop iteration (the 20th) of consumer wave 0 of every workgroup:
-// TL(k) at up to 16 points, read back by sdod_gemm_timeline()
-__device__ unsigned long long g_timeline[16 * 8192];
-#define TL(k)                                                                                               \
-    do {                                                                                                    \
-        const unsigned wg_ = blockIdx.x + gridDim.x * blockIdx.z;                                           \
-        if (tl_on && wg_ < 8192) g_timeline[wg_ * 16 + (k)] = __builtin_amdgcn_s_memtime();                \
-    } while (0)
 #else
 #define STAMP(i)
-#define TL(k)
 #endif
 
 // 8 affine-uint8 weight codes (two dwords) -> f16x8 of (q - 128), exactly: byte b next to 0x64 is the fp16 number 1024 + b
@@ -1565,7 +1550,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
         // know that neither a scalar load nor the epilogue vectors' LDS-DMA is pending, or every LDS wait inside the loop
         // degrades to lgkmcnt(0) (SMEM returns out of order; a pending "flat" LDS access forces full waits) and the
         // fragment double-buffer is lost.  (The consumers issue NO vector-memory instruction inside the loop: one issued
-        // behind the loaders' saturated queue cost ~100 ns of the wave's time, tools/gemm_phases.py --timeline.)
+        // behind the loaders' saturated queue cost ~100 ns of the wave's time: an s_memtime timeline of an earlier form)
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_s_barrier(); // slab 0 and the first patch are in LDS (the loaders waited for them)
         int slot = 0;
@@ -2131,13 +2116,6 @@ extern "C" __attribute__((visibility("default"))) int sdod_gemm_stamps(unsigned 
 }
 #endif
 
-#ifdef SDOD_GEMM_STAMP
-extern "C" __attribute__((visibility("default"))) int sdod_gemm_timeline(unsigned long long* out, int n_wg) {
-    if (!out || n_wg <= 0 || n_wg > 8192) return 1;
-    if (hipDeviceSynchronize() != hipSuccess) return 2;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), (size_t)n_wg * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 3;
-}
-#endif
 
 extern "C" int sdod_gemm_num_tiles(void) { return kNumTiles; }
 

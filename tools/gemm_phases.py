@@ -50,7 +50,6 @@ def main():
     ap.add_argument('--split', type=int, default=1)
     ap.add_argument('--residual', action='store_true')
     ap.add_argument('--geglu', action='store_true', help='rows shapes: fused GEGLU epilogue (N = 2 x hidden, [value | gate] 16-column blocks)')
-    ap.add_argument('--timeline', action='store_true', help='halo tiles: shader-clock timeline of main-loop iterations 20 and 21 of consumer wave 0')
     args = ap.parse_args()
     lib = _lib.hip()
     lib.sdod_gemm_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -113,15 +112,6 @@ def main():
             print(f'{name:34s} {tt.value:4d} {nwg:5d} {e0.elapsed_time(e1) * 1e3:7.1f} {s[:, 4].max() - t0:7.1f} {s[:, 0].max() - t0:6.1f} '
                   f'{med(s[:, 1] - s[:, 0]):6.2f} {med(s[:, 2] - s[:, 1]):7.2f} {med(s[:, 3] - s[:, 2]):6.2f} {med(s[:, 4] - s[:, 3]):6.2f} '
                   f'{med(s[:, 4] - s[:, 0]):7.2f} {float((s[:, 4] - s[:, 0]).max()):7.2f}', flush=True)
-            if args.timeline and hasattr(lib, 'sdod_gemm_timeline'):
-                tl = np.zeros((nwg, 16), np.uint64)
-                lib.sdod_gemm_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
-                if lib.sdod_gemm_timeline(tl.ctypes.data, nwg) == 0 and tl[:, 15].min() > 0:
-                    t = tl.astype(np.int64)
-                    d = np.diff(t, axis=1)
-                    names = ['patch', 'rd1', 'mfma0', 'wait0', 'barrier', 'setup+rd0', 'mfma1', '|next it:', 'patch', 'rd1', 'mfma0', 'wait0', 'barrier', 'setup+rd0', 'mfma1']
-                    print('      shader cycles (median over WGs): ' + '  '.join(f'{n} {int(np.median(d[:, k]))}' for k, n in enumerate(names)), flush=True)
-                    print(f'      one iteration: {int(np.median(t[:, 8] - t[:, 0]))} cycles', flush=True)
 
 
 if __name__ == '__main__':
