@@ -69,6 +69,7 @@ struct GemmP {
     const float* w_off;
     int fixup;               // split-K without a reduce launch: the last slice to arrive at a tile's counter reduces (conv_halo_kernel)
     unsigned* fix_counters;  // [tiles_m * tiles_n], zero when idle (in the caller's zeroed workspace, behind the partial slabs)
+    int no_respf; // developer switch (SDOD_GEMM_RESPF=0): no early residual prefetch
     int lean; // plain row-major operands whose byte offsets fit 32 bits: the loaders take the short issue path
     // halo-patch convolution (conv_halo_kernel, tiles 37..): geometry of one workgroup's output tile and of the input patch
     // it keeps in LDS, all host-computed (halo_geometry)
@@ -737,11 +738,48 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
     const int e_m = lane & 15;
     const int e_n = (lane >> 4) * 4;
     f16* sC = smem;
+    // The residual pieces a thread will add in the store phase, requested EARLY (wave-specialised kernels, behind the main
+    // loop's last barrier): the loads land while the consumers run the epilogue arithmetic instead of exposing a full load
+    // latency in front of every store.
+    constexpr int RES_K = SPEC ? (BM * (BN / 8) + NT - 1) / NT : 1;
+    constexpr bool RES_PF = SPEC && RES_K <= 4 && TM * TN < 20;
+    f16x8 rres[RES_K];
+    bool res_ready = false;
+    auto residual_prefetch = [&]() {
+        if constexpr (RES_PF) {
+            if (p.residual == nullptr || p.no_respf || p.geglu || (p.N % 8) || (p.ldo % 8) || (p.ldr % 8)) return;
+            constexpr int CPR = BN / 8;
+#pragma unroll
+            for (int k = 0; k < RES_K; ++k) {
+                const int idx = tid + k * NT;
+                const int row = idx / CPR, ch = idx - row * CPR;
+                const int m = m0 + row, n = n0 + ch * 8;
+                rres[k] = (idx < BM * CPR && m < p.M && n < p.N) ? ldg8(p.residual + (size_t)m * p.ldr + n) : zero8();
+            }
+            res_ready = true;
+        }
+    };
     auto store_phase = [&]() {
     const int CPR = p.geglu ? BN / 16 : BN / 8; // 16-byte chunks per output tile row
         const int n_out = p.geglu ? p.N / 2 : p.N;
         const int n0_out = p.geglu ? n0 / 2 : n0;
         const bool vec_ok = (n_out % 8 == 0) && (p.ldo % 8 == 0) && (p.residual == nullptr || p.ldr % 8 == 0);
+        if constexpr (RES_PF) {
+            if (res_ready) { // same pieces, same order as the loop below; the residual is already in registers
+#pragma unroll
+                for (int k = 0; k < RES_K; ++k) {
+                    const int idx = tid + k * NT;
+                    const int row = idx / (BN / 8), ch = idx - row * (BN / 8);
+                    const int m = m0 + row, n = n0 + ch * 8;
+                    if (idx >= BM * (BN / 8) || m >= p.M || n >= p.N) continue;
+                    f16x8 v = *reinterpret_cast<const f16x8*>(sC + row * SC + ch * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)rres[k][e]);
+                    stg8(p.out + (size_t)m * p.ldo + n, v);
+                }
+                return;
+            }
+        }
         for (int idx = tid; idx < BM * CPR; idx += NT) {
             const int row = idx / CPR;
             const int ch = idx - row * CPR;
@@ -795,6 +833,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                 __syncthreads();
             }
             if (p.splits > 1) return;
+            residual_prefetch();
             __syncthreads(); // the consumers have staged the output tile
             STAMP(3);
             store_phase();
@@ -1016,6 +1055,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
         return;
     }
 
+    if constexpr (SPEC) residual_prefetch();
     if (p.geglu) {
         // 16-column blocks alternate [value | gate]; both live in the SAME lane (acc[i][j], acc[i][j+1]), so GEGLU is a
         // register-level product and the tile that goes to memory is half as wide
@@ -2229,6 +2269,10 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     }
     p.lean = (d->a_mode == SDOD_A_ROWS && !d->k_tail && (unsigned long long)d->M * d->lda * 2 < (1ull << 32) &&
               (unsigned long long)d->N * d->ldw * 2 < (1ull << 32) && !lean_disabled()) ? 1 : 0;
+    {
+        static const bool respf_off = [] { const char* e2 = std::getenv("SDOD_GEMM_RESPF"); return e2 && e2[0] == '0'; }();
+        p.no_respf = respf_off ? 1 : 0;
+    }
     const Plan pl = make_plan(d);
     SDOD_REQUIRE(!(d->geglu && (pl.tile == 21 || pl.tile == 22 || pl.tile == 31 || pl.tile == 35)), "geglu needs a tile with an even number of 16-column blocks per wave");
     SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln || d->wq) || pl.tile >= 6, "geglu / tail segment / bias2 / ln / uint8 weights need an LDS-DMA tile (6..45)");
