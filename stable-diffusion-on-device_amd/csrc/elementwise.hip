@@ -7,6 +7,7 @@
 //   image_to_u8         context.cpp:392-395
 // and the PLMS/DDIM arithmetic of config 1's CPU reference (ldm PLMSSampler; not in /root/reference).
 #include "common.h"
+#include <atomic>
 #include "sdod_hip.h"
 #include "host_util.h"
 
@@ -525,14 +526,20 @@ extern "C" int sdod_l2_prefetch(const void* ptr, size_t bytes, void* stream) {
     SDOD_REQUIRE(ptr != nullptr && ((uintptr_t)ptr & 3) == 0, "null / unaligned pointer");
     const size_t lines = bytes / 128;
     if (lines == 0) return 0;
-    static unsigned* sink[64] = {};
+    static std::atomic<unsigned*> sink[64]; // one dump word per device (first use may race between threads: CAS, loser frees)
     int dev = 0;
     SDOD_HIP_CHECK(hipGetDevice(&dev));
     SDOD_REQUIRE(dev >= 0 && dev < 64, "device index");
-    if (!sink[dev]) SDOD_HIP_CHECK(hipMalloc((void**)&sink[dev], 256));
+    unsigned* cur = sink[dev].load(std::memory_order_acquire);
+    if (!cur) {
+        unsigned* fresh = nullptr;
+        SDOD_HIP_CHECK(hipMalloc((void**)&fresh, 256));
+        if (sink[dev].compare_exchange_strong(cur, fresh, std::memory_order_acq_rel)) cur = fresh;
+        else (void)hipFree(fresh);
+    }
     // few workgroups on purpose: the point is bytes in flight on an otherwise idle HBM, not CUs taken from the main chain
     const int blocks = (int)std::min<size_t>(48, (lines + 255) / 256);
-    SDOD_LAUNCH(l2_prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned*)ptr, lines, sink[dev]);
+    SDOD_LAUNCH(l2_prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned*)ptr, lines, cur);
     SDOD_HIP_CHECK(hipGetLastError());
     return 0;
     SDOD_CATCH
