@@ -850,6 +850,7 @@ struct GnGridP {
     int N, HW, C0, C1, C, G, Cg;
     int cp, rp;       // 16-byte chunks per pixel row; pixel rows per pass of the 512 threads
     int wpi, ppw, nwg; // workgroups per image, pixels per workgroup, workgroups in the grid
+    int nloop;         // passes of KMAX vectors per thread (1: the pixels stay in registers between the phases)
     float eps;
     int silu;
 };
@@ -879,22 +880,28 @@ __global__ __launch_bounds__(512) void gn_grid_kernel(const GnGridP p) {
     const float shB = (active && eb < 8) ? (float)*src(row0, (gA + 1) * p.Cg) : 0.f;
     float pilot = 0.f;
     if (tid < p.G) pilot = (float)*src(row0, tid * p.Cg);
+    // nloop == 1: the workgroup's pixels stay in registers between the two phases.  nloop > 1 (the VAE's 512x512 maps: more than
+    // KMAX vectors per thread): the statistics phase streams them KMAX at a time and the apply phase reads them again -- from
+    // the Infinity Cache, which holds the whole map -- still ONE launch instead of the statistics + apply pair.
+    const int nloop = p.nloop;
     f16x8 v[KMAX];
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        const int pix = pix_begin + r0 + k * p.rp;
-        v[k] = (active && pix < pix_end) ? ldg8(src(row0 + pix, c0)) : zero8();
-    }
     float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+    for (int l = 0; l < nloop; ++l) {
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        const bool ok = active && (pix_begin + r0 + k * p.rp) < pix_end;
+        for (int k = 0; k < KMAX; ++k) {
+            const int pix = pix_begin + r0 + (l * KMAX + k) * p.rp;
+            v[k] = (active && pix < pix_end) ? ldg8(src(row0 + pix, c0)) : zero8();
+        }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool inA = e < eb;
-            const float d = ok ? (float)v[k][e] - (inA ? shA : shB) : 0.f;
-            a1 += inA ? d : 0.f; a2 += inA ? d * d : 0.f;
-            b1 += inA ? 0.f : d; b2 += inA ? 0.f : d * d;
+        for (int k = 0; k < KMAX; ++k) {
+            const bool ok = active && (pix_begin + r0 + (l * KMAX + k) * p.rp) < pix_end;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool inA = e < eb;
+                const float d = ok ? (float)v[k][e] - (inA ? shA : shB) : 0.f;
+                a1 += inA ? d : 0.f; a2 += inA ? d * d : 0.f;
+                b1 += inA ? 0.f : d; b2 += inA ? 0.f : d * d;
+            }
         }
     }
     red[tid * 4 + 0] = a1; red[tid * 4 + 1] = a2; red[tid * 4 + 2] = b1; red[tid * 4 + 3] = b2;
@@ -1000,18 +1007,27 @@ __global__ __launch_bounds__(512) void gn_grid_kernel(const GnGridP p) {
         s8[e] = sc[c0 + e];
         t8[e] = sh[c0 + e];
     }
+    for (int l = 0; l < nloop; ++l) {
+        if (nloop > 1) { // streamed map: this thread's pixels again (its own: y == x stays safe)
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        const int pix = pix_begin + r0 + k * p.rp;
-        if (pix < pix_end) {
-            f16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float f = (float)v[k][e] * s8[e] + t8[e];
-                if (p.silu) f = silu_f(f);
-                o[e] = (f16)f;
+            for (int k = 0; k < KMAX; ++k) {
+                const int pix = pix_begin + r0 + (l * KMAX + k) * p.rp;
+                v[k] = pix < pix_end ? ldg8(src(row0 + pix, c0)) : zero8();
             }
-            stg8(p.y + (row0 + pix) * p.C + c0, o);
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int pix = pix_begin + r0 + (l * KMAX + k) * p.rp;
+            if (pix < pix_end) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = (float)v[k][e] * s8[e] + t8[e];
+                    if (p.silu) f = silu_f(f);
+                    o[e] = (f16)f;
+                }
+                stg8(p.y + (row0 + pix) * p.C + c0, o);
+            }
         }
     }
 }
@@ -1044,9 +1060,10 @@ static int gn_grid_plan(int n, int hw, int c0, int c1, int groups, GnGridP* out)
     const int cp = c / 8, rp = 512 / cp;
     const int ppw = (hw + wpi - 1) / wpi;
     const int k = (ppw + rp - 1) / rp;
-    if (k > 16) return 0;
+    if (k > 16 * 8) return 0;
     if (out) {
         out->cp = cp; out->rp = rp; out->wpi = wpi; out->ppw = ppw; out->nwg = wpi * n;
+        out->nloop = k <= 16 ? 1 : (k + 15) / 16;
     }
     return k <= 4 ? 4 : k <= 8 ? 8 : 16;
 }
