@@ -1906,9 +1906,12 @@ const TileCfg kTiles[] = {{0, 0},     {128, 128}, {128, 64}, {64, 64},   {256, 1
                           // 32..36: wave-specialised, two slabs per barrier
                           {64, 64}, {128, 64}, {64, 128}, {64, 160}, {128, 128},
                           // 37..45: halo-patch 3x3 convolution (conv_halo_kernel)
-                          {64, 160}, {128, 80}, {128, 160}, {64, 80}, {256, 32}, {128, 32}, {256, 64}, {128, 64}, {64, 64}};
-constexpr int kNumTiles = 45;
-constexpr int kFirstHaloTile = 37;
+                          {64, 160}, {128, 80}, {128, 160}, {64, 80}, {256, 32}, {128, 32}, {256, 64}, {128, 64}, {64, 64},
+                          // 46..48: wave-specialised 32-row tiles for the small-M Linear layers (M = 512 at the 16x16 level: twice the
+                          // workgroups of a 64-row tile at three quarters of its bytes per slab)
+                          {32, 64}, {32, 128}, {32, 160}};
+constexpr int kNumTiles = 48;
+constexpr int kFirstHaloTile = 37, kLastHaloTile = 45;
 // {STAGES} of the halo tiles (WM x WN is 2x2 for the 160- and 64-wide square-ish ones, 4x1 for the tall ones: launch switch)
 const int kHaloStages[] = {4, 4, 3, 4, 6, 6, 4, 4, 4};
 
@@ -1986,7 +1989,7 @@ struct Plan {
 
 // Can halo tile `tile` run descriptor d?  Fills the geometry fields of *p (may be null) and the LDS bytes of the launch.
 bool halo_geometry(const sdod_gemm_desc* d, int tile, GemmP* p, size_t* smem_bytes) {
-    if (tile < kFirstHaloTile || tile > kNumTiles) return false;
+    if (tile < kFirstHaloTile || tile > kLastHaloTile) return false;
     if (d->a_mode != SDOD_A_CONV3X3 || d->ksize == 1 || d->stride != 1 || d->wq || d->geglu || d->ln || d->bias_on_m) return false;
     if (d->c0 <= 0 || d->c0 % 64 || d->c1 % 64 || d->h_in <= 0 || d->w_in <= 0 || d->n_img <= 0) return false;
     if (d->upsample && d->k_tail) return false;
@@ -2046,7 +2049,7 @@ Plan make_plan(const sdod_gemm_desc* d) {
     int tile = d->tile;
     const bool fused = d->geglu || d->k_tail || d->ln || d->wq;
     if (fused && (tile < 6 || tile > kNumTiles)) tile = 14; // fusions live in the LDS-DMA kernel family only
-    if (d->geglu && (tile == 21 || tile == 22 || tile == 31 || tile == 35)) tile = 14;
+    if (d->geglu && (tile == 21 || tile == 22 || tile == 31 || tile == 35 || tile == 48)) tile = 14;
     if (d->wq && !(tile == 8 || tile == 13 || tile == 23 || tile == 24 || (tile >= 27 && tile <= 31))) tile = 23; // uint8-weight variants
     if (d->wq && d->geglu && tile == 31) tile = 23;  // value/gate pairing needs an even number of 16-column blocks per wave
     if (tile <= 0 || tile > kNumTiles) {
@@ -2075,7 +2078,7 @@ Plan make_plan(const sdod_gemm_desc* d) {
         }
     }
     pl.main_splits = 0;
-    if (tile >= kFirstHaloTile && halo_geometry(d, tile, nullptr, nullptr)) { // (a descriptor it cannot run is rejected at launch)
+    if (tile >= kFirstHaloTile && tile <= kLastHaloTile && halo_geometry(d, tile, nullptr, nullptr)) { // (a descriptor it cannot run is rejected at launch)
         // whole 64-channel chunks (9 tap slabs) per split; the 1x1 tail, if any, is one more slice
         const int nmain = (d->c0 + d->c1) / BK;
         int want = d->split_k;
@@ -2103,7 +2106,7 @@ Plan make_plan(const sdod_gemm_desc* d) {
 namespace {
 constexpr size_t kFixupCounters = (size_t)64 << 10;
 bool fixup_applies(const sdod_gemm_desc* d, const Plan& pl) {
-    if (!d->fix_counters || d->phase != 0 || pl.splits <= 1 || pl.tile < kFirstHaloTile || d->N % 4 != 0) return false;
+    if (!d->fix_counters || d->phase != 0 || pl.splits <= 1 || pl.tile < kFirstHaloTile || pl.tile > kLastHaloTile || d->N % 4 != 0) return false;
     const size_t tiles = (size_t)((d->M + kTiles[pl.tile].bm - 1) / kTiles[pl.tile].bm) * ((d->N + kTiles[pl.tile].bn - 1) / kTiles[pl.tile].bn);
     return tiles <= kFixupCounters && halo_geometry(d, pl.tile, nullptr, nullptr);
 }
@@ -2174,7 +2177,8 @@ extern "C" int sdod_gemm_tile_info(int tile, int out[7]) {
         {64, 64, 2, 2, 4, 1, 2}, {128, 64, 2, 2, 3, 1, 2}, {64, 128, 2, 2, 3, 1, 2}, {64, 160, 2, 2, 2, 1, 2}, {128, 128, 2, 2, 2, 1, 2},
         // SPEC column 2 = conv_halo_kernel<BM, BN, WM, WN, STAGES>
         {64, 160, 2, 2, 4, 2, 1}, {128, 80, 4, 1, 4, 2, 1}, {128, 160, 2, 2, 3, 2, 1}, {64, 80, 4, 1, 4, 2, 1}, {256, 32, 4, 1, 6, 2, 1},
-        {128, 32, 4, 1, 6, 2, 1}, {256, 64, 4, 1, 4, 2, 1}, {128, 64, 2, 2, 4, 2, 1}, {64, 64, 2, 2, 4, 2, 1}};
+        {128, 32, 4, 1, 6, 2, 1}, {256, 64, 4, 1, 4, 2, 1}, {128, 64, 2, 2, 4, 2, 1}, {64, 64, 2, 2, 4, 2, 1},
+        {32, 64, 2, 2, 6, 1, 1}, {32, 128, 1, 4, 6, 1, 1}, {32, 160, 2, 2, 4, 1, 1}};
     static_assert(sizeof(kInfo) / sizeof(kInfo[0]) == kNumTiles + 1, "one row per tile");
     if (tile < 1 || tile > kNumTiles || !out) return sdod::INVALID_ARGUMENT;
     for (int i = 0; i < 7; ++i) out[i] = kInfo[tile][i];
@@ -2274,12 +2278,12 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         p.no_respf = respf_off ? 1 : 0;
     }
     const Plan pl = make_plan(d);
-    SDOD_REQUIRE(!(d->geglu && (pl.tile == 21 || pl.tile == 22 || pl.tile == 31 || pl.tile == 35)), "geglu needs a tile with an even number of 16-column blocks per wave");
-    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln || d->wq) || pl.tile >= 6, "geglu / tail segment / bias2 / ln / uint8 weights need an LDS-DMA tile (6..45)");
+    SDOD_REQUIRE(!(d->geglu && (pl.tile == 21 || pl.tile == 22 || pl.tile == 31 || pl.tile == 35 || pl.tile == 48)), "geglu needs a tile with an even number of 16-column blocks per wave");
+    SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln || d->wq) || pl.tile >= 6, "geglu / tail segment / bias2 / ln / uint8 weights need an LDS-DMA tile (6..48)");
     p.splits = pl.splits;
     p.kt_per_split = pl.kt_per_split;
     size_t halo_smem = 0;
-    if (pl.tile >= kFirstHaloTile) {
+    if (pl.tile >= kFirstHaloTile && pl.tile <= kLastHaloTile) {
         SDOD_REQUIRE(halo_geometry(d, pl.tile, &p, &halo_smem), "this halo-patch tile does not take the convolution (3x3, stride 1, tile rows must divide the image)");
         p.h_main_splits = pl.main_splits;
         if (fixup_applies(d, pl)) {
@@ -2361,6 +2365,9 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     case 33: e = launch_glds<128, 64, 2, 2, 3, true, false, 2>(p, grid, st); break;
     case 34: e = launch_glds<64, 128, 2, 2, 3, true, false, 2>(p, grid, st); break;
     case 35: e = launch_glds<64, 160, 2, 2, 2, true, false, 2>(p, grid, st); break;
+    case 46: e = launch_glds<32, 64, 2, 2, 6, true>(p, grid, st); break;
+    case 47: e = launch_glds<32, 128, 1, 4, 6, true>(p, grid, st); break;
+    case 48: e = launch_glds<32, 160, 2, 2, 4, true>(p, grid, st); break;
     default: e = launch_glds<128, 128, 2, 2, 2, true, false, 2>(p, grid, st); break;
     }
     SDOD_HIP_CHECK(e);

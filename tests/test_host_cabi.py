@@ -176,7 +176,7 @@ def test_halo_patch_tile_planning_without_a_gpu():
     # tile metadata for profilers: SPEC column 2 marks conv_halo_kernel<BM, BN, WM, WN, STAGES>
     info = (ctypes.c_int * 7)()
     assert lib.sdod_gemm_tile_info(38, info) == 0 and list(info) == [128, 80, 4, 1, 4, 2, 1]
-    assert lib.sdod_gemm_num_tiles() >= 45
+    assert lib.sdod_gemm_num_tiles() >= 48
 
 
 def test_group_norm_path_selection_without_a_gpu():

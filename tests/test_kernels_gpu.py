@@ -59,6 +59,8 @@ def test_library_and_device():
     # two slabs per barrier (32 64x64, 33 128x64, 34 64x128, 35 64x160, 36 128x128): odd and even slab counts, K = 64
     (200, 72, 64, 32), (128, 1280, 1280, 32), (333, 72, 704, 32), (333, 72, 640, 33), (100, 136, 192, 34), (8192, 320, 320, 35),
     (300, 200, 192, 35), (1000, 320, 1280, 36), (300, 200, 448, 36),
+    # 32-row wave-specialised tiles (46 32x64, 47 32x128, 48 32x160)
+    (512, 1280, 1280, 46), (100, 72, 64, 46), (512, 1280, 1280, 47), (70, 136, 192, 47), (512, 1280, 1280, 48), (333, 200, 640, 48),
 ])
 def test_gemm_rows(m, n, k, tile):
     from sdod.amd import ops
@@ -122,7 +124,7 @@ def test_gemm_uint8_weight_streaming(case, tile):
     check(out, ref, name=f'uint8 weights {case} tile{tile}')
 
 
-@pytest.mark.parametrize('tile', [0, 6, 8, 9, 10, 17, 20, 21, 22, 23, 25, 27, 29, 31, 32, 33, 35, 36])
+@pytest.mark.parametrize('tile', [0, 6, 8, 9, 10, 17, 20, 21, 22, 23, 25, 27, 29, 31, 32, 33, 35, 36, 46, 47, 48])
 @pytest.mark.parametrize('split', [2, 5, 16])
 def test_gemm_split_k(split, tile):
     from sdod.amd import ops
@@ -159,7 +161,7 @@ def conv_ref(x_nhwc, w_krsc, bias, stride=1, upsample=False):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
-@pytest.mark.parametrize('tile', [0, 6, 7, 8, 9, 10, 11, 12, 13, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36])
+@pytest.mark.parametrize('tile', [0, 6, 7, 8, 9, 10, 11, 12, 13, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 46, 47, 48])
 @pytest.mark.parametrize('n,h,w,cin,cout,stride,ups', [
     (2, 16, 16, 64, 128, 1, False), (1, 9, 7, 128, 64, 1, False), (2, 16, 16, 64, 64, 2, False),
     (1, 8, 8, 128, 128, 1, True), (2, 64, 64, 320, 320, 1, False), (2, 8, 8, 1280, 1280, 1, False),
@@ -205,7 +207,7 @@ def test_conv1x1_two_sources():
     check(out, ref, name='conv1x1 concat')
 
 
-@pytest.mark.parametrize('tile', [0, 6, 8, 10, 14, 16, 20, 21, 22, 23, 25, 26, 27, 29, 30, 31, 32, 34, 36])
+@pytest.mark.parametrize('tile', [0, 6, 8, 10, 14, 16, 20, 21, 22, 23, 25, 26, 27, 29, 30, 31, 32, 34, 36, 46, 47, 48])
 def test_gemm_fused_geglu(tile):
     """ff.net.0.proj + GEGLU in one launch: weight rows interleaved in 16-row [value | gate] blocks (tiles 21/22 cannot
     pair value and gate inside one wave: the planner must fall back, not skip the epilogue)"""
@@ -225,7 +227,7 @@ def test_gemm_fused_geglu(tile):
     check(out, ref, name=f'fused geglu tile{tile}')
 
 
-@pytest.mark.parametrize('tile', [0, 6, 8, 11, 14, 18, 20, 21, 22, 23, 25, 26, 27, 28, 30, 31, 32, 33, 35, 36])
+@pytest.mark.parametrize('tile', [0, 6, 8, 11, 14, 18, 20, 21, 22, 23, 25, 26, 27, 28, 30, 31, 32, 33, 35, 36, 46, 47, 48])
 @pytest.mark.parametrize('m,c,n', [(600, 320, 960), (8192, 320, 320), (200, 1280, 1280)])
 def test_gemm_with_folded_layer_norm(tile, m, c, n):
     """LayerNorm -> Linear in one launch: row statistics gathered inside the GEMM, gamma folded into W"""
@@ -259,7 +261,7 @@ def test_gemm_ln_fold_with_geglu():
     check(out, ref, tol=3e-3, name='ln-fold + geglu')
 
 
-@pytest.mark.parametrize('tile', [0, 7, 9, 12, 14, 23, 26, 27, 31, 32, 36])
+@pytest.mark.parametrize('tile', [0, 7, 9, 12, 14, 23, 26, 27, 31, 32, 36, 46, 48])
 def test_conv3x3_with_skip_tail_segment(tile):
     """ResBlock: out_layers.3 (3x3 on h) + skip_connection (1x1 on the concatenated block input) as ONE GEMM"""
     from sdod.amd import ops
