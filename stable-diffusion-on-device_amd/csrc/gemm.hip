@@ -1298,7 +1298,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
     const int e_n = (lane >> 4) * 4;
 
     // per-column epilogue vectors -> LDS, issued before anything else (they are older than every slab / patch)
-    float* colv = reinterpret_cast<float*>(smem_raw + p.h_colv_off); // [2][BN]: bias, bias2
+    float* colv = reinterpret_cast<float*>(smem_raw + p.h_colv_off); // [2][BN] fp32: bias, bias2; then [BN] fp16: the tile's row bias
+    // the per-image row bias (time embedding) rides along when the tile lies inside ONE image: fetched in the epilogue it
+    // exposes a full load latency per launch
+    constexpr bool RB_LDS_OK = TM * TN < 20; // (the 128x160 tile has no register to spare for the extra path)
+    const bool rb_lds = RB_LDS_OK && p.row_bias != nullptr && (p.N & 1) == 0 && (p.ldrb & 1) == 0 && ((uintptr_t)p.row_bias & 3) == 0 &&
+                        m0 / p.rows_per_img == (min(m0 + BM, p.M) - 1) / p.rows_per_img;
     {
         constexpr int CHUNKS = (BN + 63) / 64;
         const float* zf = reinterpret_cast<const float*>(zeros) + lane;
@@ -1308,6 +1313,15 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
             const float* base = vec == 0 ? p.bias : p.bias2;
             const float* g = (base != nullptr && n < p.N) ? base + n : zf;
             if (c < BN) __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(colv + vec * BN + q * 64), 4, 0, 0);
+        }
+        if (rb_lds) { // BN halves = BN / 2 dwords: one or two wave-instructions, by the waves the loop above leaves idle
+            constexpr int RCH = (BN / 2 + 63) / 64;
+            const f16* rb = p.row_bias + (size_t)(m0 / p.rows_per_img) * p.ldrb;
+            for (int job = wave - 2 * CHUNKS; job >= 0 && job < RCH; job += 8) { // wave-uniform
+                const int c = job * 64 + lane, n = n0 + 2 * c;
+                const float* g = n < p.N ? reinterpret_cast<const float*>(rb + n) : zf;
+                if (c < BN / 2) __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(colv + 2 * BN + job * 64), 4, 0, 0);
+            }
         }
     }
 
@@ -1772,7 +1786,17 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] + b1[r]) + b2[r];
     }
-    if (p.row_bias != nullptr) {
+    if (rb_lds) {
+        const f16* rbl = reinterpret_cast<const f16*>(colv + 2 * BN);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const f16x4 t = *reinterpret_cast<const f16x4*>(rbl + wn * WTN + j * 16 + e_n);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)t[r];
+        }
+    } else if (p.row_bias != nullptr) {
         const bool rb_vec = (p.ldrb & 3) == 0 && ((uintptr_t)p.row_bias & 7) == 0 && (p.N & 3) == 0;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -2026,7 +2050,7 @@ bool halo_geometry(const sdod_gemm_desc* d, int tile, GemmP* p, size_t* smem_byt
     const size_t tail = d->k_tail ? (size_t)halo_tail_stages(BMt, BNt, stages) * (BMt + BNt) * 128 : 0;
     const size_t ctile = (size_t)BMt * (BNt + 8) * sizeof(f16);
     const size_t body = std::max(std::max(halo, tail), ctile);
-    const size_t total = body + (size_t)2 * BNt * sizeof(float);
+    const size_t total = body + (size_t)2 * BNt * sizeof(float) + (size_t)BNt * sizeof(f16) + 256; // + the row-bias vector (whole DMA instructions)
     if (total > 160 * 1024) return false;
     if (smem_bytes) *smem_bytes = total;
     if (p) {
