@@ -93,9 +93,10 @@ typedef struct sdod_gemm_desc {
     /* --- int8 weight streaming (LDS-DMA kernel family only; BASELINE config 5, the reference's `quantize=8` path,
      * todlc.py:105-108): w holds the affine-uint8 CODES of the reference's encoding real = (q + offset) * scale
      * (qnn_context.cpp:1018-1033), one byte per element, row stride ldw BYTES; the slab is streamed as bytes (half the
-     * weight traffic of fp16) and expanded to fp16 (q - 128, exact) on the fragment read.  Per output column n:
-     * w_scale[n] = scale, w_off[n] = offset + 128 (fp32), so fused parameter groups may mix tensors with different
-     * encodings.  out = act(alpha * w_scale[n] * (sum_k A (q - 128) + w_off[n] * sum_k A) + bias ...).  Not with ln / k_tail. */
+     * weight traffic of fp16) and expanded to the integer q + offset in fp16 (exact) on the fragment read.  Per output
+     * column n: w_scale[n] = scale, w_off[n] = offset + 128 (fp32 holding an INTEGER, offset in [-1024, 0] -- the QNN
+     * zero point of a uint8 tensor is in [-255, 0]), so fused parameter groups may mix tensors with different
+     * encodings.  out = act(alpha * w_scale[n] * sum_k A (q + offset[n]) + bias ...).  Not with ln / k_tail. */
     int wq;
     const void* w_scale;           /* fp32 [N] */
     const void* w_off;             /* fp32 [N] */

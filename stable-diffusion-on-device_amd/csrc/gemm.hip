@@ -63,7 +63,7 @@ struct GemmP {
     int tiles_m, tiles_n;
     // int8 weight streaming (config 5, "mirrors the QNN quant path"): W holds the affine-uint8 codes q of the reference's
     // encoding real = (q + offset) * scale (qnn_context.cpp:1018-1033), one byte per element, [N][ldw bytes]; per output
-    // column n: w_scale[n] = scale, w_off[n] = offset + 128 (as float).  out = scale * (sum_k A (q - 128) + w_off * sum_k A).
+    // column n: w_scale[n] = scale, w_off[n] = offset + 128 (as float; offset an INTEGER in [-1024, 0]).  out = scale * sum_k A (q + offset).
     int wq;
     const float* w_scale;
     const float* w_off;
@@ -438,25 +438,34 @@ __device__ unsigned long long g_stamp[8 * 8192];
 #endif
 
 // 8 affine-uint8 weight codes (two dwords) -> f16x8 of (q - 128), exactly: byte b next to 0x64 is the fp16 number 1024 + b
-// (v_perm_b32 builds two of them per instruction), and one packed subtraction of 1152 centres it.  4 VALU per 8 weights.
-SDOD_DEVICE f16x8 u8x8_to_f16(u32x2 d) {
+// (v_perm_b32 builds two of them per instruction), and one packed subtraction of z = 1024 - offset turns it into the integer
+// q + offset of the affine encoding, exactly (|q + offset| <= 2048): the zero point never reaches the accumulators, so no
+// row sums of A are needed.  4 + 4 VALU per 8 weights.
+SDOD_DEVICE f16x8 u8x8_to_f16(u32x2 d, f16 z) {
     const uint32_t c64 = 0x64646464u;
     typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
-    u32x4v w;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 nz = {(_Float16)-z, (_Float16)-z};
+    uint32_t w[4];
     w[0] = __builtin_amdgcn_perm(c64, d[0], 0x04010400u);
     w[1] = __builtin_amdgcn_perm(c64, d[0], 0x04030402u);
     w[2] = __builtin_amdgcn_perm(c64, d[1], 0x04010400u);
     w[3] = __builtin_amdgcn_perm(c64, d[1], 0x04030402u);
-    f16x8 h = __builtin_bit_cast(f16x8, w);
-    const f16x8 c = {(f16)1152.f, (f16)1152.f, (f16)1152.f, (f16)1152.f, (f16)1152.f, (f16)1152.f, (f16)1152.f, (f16)1152.f};
-    return h - c;
+    u32x4v o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { // v_pk_add_f16, spelled out: the vector form of the subtraction is scalarised when z is a register
+        uint32_t r;
+        asm("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(w[i]), "v"(nz));
+        o[i] = r;
+    }
+    return __builtin_bit_cast(f16x8, o);
 }
 // fragment of weight row `row` (tile-local), K half `ks`, lane chunk `fc` (0..3), from the uint8 slab image (8-row groups at a
 // 1 KiB pitch, 64-byte rows, 16-byte chunks swizzled with (row >> 2) & 3)
-SDOD_DEVICE f16x8 wq_frag(const f16* sB, int row, int ks, int fc) {
+SDOD_DEVICE f16x8 wq_frag(const f16* sB, int row, int ks, int fc, f16 z) {
     const unsigned char* base = reinterpret_cast<const unsigned char*>(sB) + (row >> 3) * 1024 + (row & 7) * 64;
     const int chunk = (ks * 2 + (fc >> 1)) ^ ((row >> 2) & 3);
-    return u8x8_to_f16(*reinterpret_cast<const u32x2*>(base + chunk * 16 + (fc & 1) * 8));
+    return u8x8_to_f16(*reinterpret_cast<const u32x2*>(base + chunk * 16 + (fc & 1) * 8), z);
 }
 
 // SPEC = wave specialisation: the workgroup is WM*WN CONSUMER waves (one per SIMD: fragment reads + MFMA, each owning a
@@ -711,7 +720,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                 float var = a2 / (float)p.K - mean * mean;
                 var = var < 0.f ? 0.f : var;
                 const int r = (i * NL + lw) * 8 + lrow;
-                ln_stats[2 * r] = WQ ? a1 : mean; // uint8 weights: the plain row sum of A over this workgroup's K range
+                ln_stats[2 * r] = mean;
                 ln_stats[2 * r + 1] = 1.0f / sqrtf(var + p.ln_eps);
             }
         }
@@ -730,7 +739,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
             const int vec = job / CHUNKS, q = job - vec * CHUNKS;
             const int c = q * 64 + lane, n = n0 + c;
             const float* base = vec == 0 ? ((p.bias != nullptr && !p.bias_on_m) ? p.bias : nullptr) : vec == 1 ? p.bias2
-                              : vec == 2 ? (p.ln ? p.ln_s : WQ ? p.w_off : nullptr) : (WQ ? p.w_scale : nullptr);
+                              : vec == 2 ? (p.ln ? p.ln_s : nullptr) : (WQ ? p.w_scale : nullptr);
             const float* g = (base != nullptr && n < p.N) ? base + n : zf;
             if (c < BN) __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(colv + vec * BN + q * 64), 4, 0, 0);
         }
@@ -822,13 +831,13 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                     wait_younger<LOADS, (STAGES - 2) * KSUB>(max(0, nkt - it - KSUB));
                     __builtin_amdgcn_s_barrier(); // ... and everybody's; the previous group is no longer read
                 }
-                if (p.ln || WQ) ln_accumulate(smem + (it % NSLOT) * STAGE);
+                if (p.ln) ln_accumulate(smem + (it % NSLOT) * STAGE);
                 if (it + AHEAD < nkt) issue_tile(kt_begin + it + AHEAD, (it + AHEAD) % NSLOT);
             }
             wait_vmcnt<0>();
             __syncthreads();
             STAMP(2);
-            if (p.ln || WQ) {
+            if (p.ln) {
                 ln_finalize();
                 __syncthreads();
             }
@@ -846,6 +855,19 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
     }
 
     // ---------------- unified program (SPEC = false) / CONSUMER program (SPEC = true) ----------------
+    // uint8 weights: z = 1024 - offset of the weight rows this lane reads fragments of (w_off holds offset + 128); requested
+    // before the first slab so that the load is the oldest thing in flight
+    f16 wq_z[TN];
+    if constexpr (WQ) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WTN + j * 16 + frag_row;
+            wq_z[j] = (f16)(1152.0f - (n < p.N ? p.w_off[n] : 128.0f));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wq_z[j] = (f16)0.f;
+    }
     if constexpr (!SPEC) {
         if (lean) setup_lean();
         else setup_rows();
@@ -956,7 +978,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                     xa[ks][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WTM + i * 16 + frag_row, ks * 4 + frag_chunk));
     #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    wb[ks][j] = WQ ? wq_frag(sB, wn * WTN + j * 16 + frag_row, ks, frag_chunk)
+                    wb[ks][j] = WQ ? wq_frag(sB, wn * WTN + j * 16 + frag_row, ks, frag_chunk, wq_z[j])
                                      : *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
             }
             } else {
@@ -969,7 +991,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                 }
             }
             if constexpr (!SPEC) {
-                if (p.ln || WQ) ln_accumulate(sA);
+                if (p.ln) ln_accumulate(sA);
             }
             if constexpr (!SPEC) {
                 if (it + AHEAD < nkt && !(dbg & 2)) issue_tile(kt_begin + it + AHEAD, (it + AHEAD) % NSLOT);
@@ -983,7 +1005,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                             xa[0][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WTM + i * 16 + frag_row, ks * 4 + frag_chunk));
     #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            wb[0][j] = WQ ? wq_frag(sB, wn * WTN + j * 16 + frag_row, ks, frag_chunk)
+                            wb[0][j] = WQ ? wq_frag(sB, wn * WTN + j * 16 + frag_row, ks, frag_chunk, wq_z[j])
                                             : *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WTN + j * 16 + frag_row, ks * 4 + frag_chunk));
     #pragma unroll
                         for (int j = 0; j < TN; ++j)
@@ -1017,22 +1039,19 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
     __syncthreads(); // all fragment reads done before the epilogue tile overwrites the ring
     STAMP(2);
 
-    if (p.ln || WQ) {
+    if (p.ln) {
         if constexpr (!SPEC) ln_finalize();
         __syncthreads();
     }
     if (WQ) {
-        // affine-uint8 weights: acc holds sum_k A (q - 128); out = scale_n * (acc + (offset_n + 128) * sum_k A)
+        // affine-uint8 weights: acc holds sum_k A (q + offset_n), exactly the integer codes; out = scale_n * acc
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const float rsum = ln_stats[2 * (wm * WTM + i * 16 + e_m)];
+        for (int j = 0; j < TN; ++j) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(colv + 3 * BN + wn * WTN + j * 16 + e_n);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nl = wn * WTN + j * 16 + e_n;
-                const f32x4 of = *reinterpret_cast<const f32x4*>(colv + 2 * BN + nl), sc = *reinterpret_cast<const f32x4*>(colv + 3 * BN + nl);
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] + rsum * of[r]) * sc[r];
-            }
+                for (int r = 0; r < 4; ++r) acc[i][j][r] *= sc[r];
         }
     }
     if (p.splits > 1) {
@@ -1235,7 +1254,12 @@ constexpr int halo_tail_stages(int bm, int bn, int stages) {
 //     h_main_splits) whose workgroups run the plain ring program (A and B slabs by the loaders) on the tail columns; the
 //     partial slabs meet in splitk_reduce_kernel like any split.
 // Output rows of a tile are consecutive (a row segment, whole rows, or whole images), so the epilogue is the GEMM's.
-template <int BM, int BN, int WM, int WN, int STAGES>
+//   * WQ = affine-uint8 weights (config 5): the weight slabs are 64-byte rows streamed as bytes (lanes 0..31 of a DMA
+//     instruction), the consumers expand a fragment to the integers q + offset in fp16 right before its MFMAs (u8x8_to_f16:
+//     8 VALU per 8 x 16 weights, amortised over the TM row blocks -- tiles with TM >= 4 hide it under the matrix pipe) and
+//     the per-column scale is applied to the accumulators before anything else sees them.  No 1x1 tail (the host keeps the
+//     skip convolution of a uint8 graph a separate GEMM: its tensor has its own encoding).
+template <int BM, int BN, int WM, int WN, int STAGES, bool WQ = false>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16* __restrict__ zeros) {
     static_assert(WM * WN == 4, "four consumer waves (one per SIMD) + four loader waves");
     constexpr int NL = 4;
@@ -1276,7 +1300,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
     const int tile_n = lid - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int split = blockIdx.z;
-    const bool tail_wg = p.k_tail != 0 && split == p.h_main_splits;
+    const bool tail_wg = !WQ && p.k_tail != 0 && split == p.h_main_splits;
     const int cin = p.c0 + p.c1;
     // slabs of this workgroup: [kt_begin, kt_end) of the 9 * (cin / 64) tap slabs, or all tail slabs
     int kt_begin, kt_end;
@@ -1323,6 +1347,13 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
                 if (c < BN / 2) __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(colv + 2 * BN + job * 64), 4, 0, 0);
             }
         }
+        if constexpr (WQ) { // per-column scale of the uint8 encoding, behind the row-bias vector; by the waves counted from the top
+            for (int q = 7 - wave; q < CHUNKS; q += 8) {
+                const int c = q * 64 + lane, n = n0 + c;
+                const float* g = n < p.N ? p.w_scale + n : zf;
+                if (c < BN) __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(colv + 2 * BN + BN / 2 + 64 + q * 64), 4, 0, 0);
+            }
+        }
     }
 
     f16* sC = smem;
@@ -1365,10 +1396,17 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
             unsigned b_off[NB];
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int n = min(n0 + (i * NL + lw) * 8 + lrow, p.N - 1);
-                b_off[i] = ((unsigned)n * (unsigned)p.ldw + (unsigned)lchunk * 8u) * 2u;
+                if constexpr (!WQ) {
+                    const int n = min(n0 + (i * NL + lw) * 8 + lrow, p.N - 1);
+                    b_off[i] = ((unsigned)n * (unsigned)p.ldw + (unsigned)lchunk * 8u) * 2u;
+                } else { // 64-byte slab rows: lanes 0..31 cover the 8 rows of the group, 16-byte pieces swizzled with (row >> 2) & 3 (wq_frag)
+                    const int r = (i * NL + lw) * 8 + ((lane & 31) >> 2);
+                    const int n = min(n0 + r, p.N - 1);
+                    b_off[i] = (unsigned)n * (unsigned)p.ldw + (unsigned)(((lane & 3) ^ ((r >> 2) & 3)) * 16); // ldw in bytes
+                }
             }
-            const f16* w_s = sgpr_pin(p.w);
+            const unsigned char* w_s = sgpr_pin(reinterpret_cast<const unsigned char*>(p.w));
+            constexpr int WB = WQ ? 1 : 2; // bytes per weight
             if (!tail_wg) {
                 constexpr int SLOT = BN * 64;
                 // ---- the patch pieces this lane fetches (one 16-byte piece per DMA round): byte offset inside either source,
@@ -1446,7 +1484,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
                         }
                         f16* sB = smem + s_slot * SLOT;
 #pragma unroll
-                        for (int i = 0; i < CNT; ++i) lds_dma16_saddr(w_s + k0, b_off[i], sB + (i * NL + lw) * 8 * 64);
+                        for (int i = 0; i < CNT; ++i)
+                            if (!WQ || lane < 32) lds_dma16_saddr(w_s + (size_t)k0 * WB, b_off[i], sB + (i * NL + lw) * 8 * 64);
                         k0 += t == 8 ? BK - 8 * cin_s : cin_s;
                         s_slot = s_slot + 1 == STAGES ? 0 : s_slot + 1;
                     });
@@ -1483,7 +1522,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
                     }
                     const int k0 = p.k_tail + kk;
 #pragma unroll
-                    for (int i = 0; i < CNT; ++i) lds_dma16_saddr(w_s + k0, b_off[i], sB + (i * NL + lw) * 8 * 64);
+                    for (int i = 0; i < CNT; ++i) lds_dma16_saddr(w_s + (size_t)k0 * WB, b_off[i], sB + (i * NL + lw) * 8 * 64);
                 };
 #pragma unroll
                 for (int s = 0; s < TAHEAD; ++s)
@@ -1520,6 +1559,13 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int b_off0 = lds_off(wn * WTN + frag_row, frag_chunk); // weight fragment (j = 0, K half 0) inside a slab
+    // uint8 weights: z = 1024 - offset of the weight rows this lane reads fragments of (w_off holds offset + 128)
+    f16 wq_z[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + frag_row;
+        wq_z[j] = WQ ? (f16)(1152.0f - (n < p.N ? p.w_off[n] : 128.0f)) : (f16)0.f;
+    }
 
     if (!tail_wg) {
         constexpr int SLOT = BN * 64;
@@ -1556,25 +1602,45 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
             }
         }
         unsigned pdelta = (unsigned)sgpr_pin(p.h_patch_halves) * 2u; // byte distance to the other patch buffer (sign flips per chunk)
-        const unsigned b_addr0 = smem_base + (unsigned)b_off0 * 2u;  // weight fragment j = 0, K half 0, ring slot 0
+        unsigned b_addr0 = smem_base + (unsigned)b_off0 * 2u;  // weight fragment j = 0, K half 0, ring slot 0
+        if constexpr (WQ) { // byte image of the slab (wq_frag): 8-row groups at 1 KiB, 64-byte rows, 8 bytes per lane and K half
+            const int row = wn * WTN + frag_row;
+            b_addr0 = smem_base + (unsigned)((row >> 3) * 1024 + (row & 7) * 64 + (((frag_chunk >> 1) ^ ((row >> 2) & 3)) << 4) + (frag_chunk & 1) * 8);
+        }
         STAMP(1);
 
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
-        f16x8 fa[2][TM], fb[2][TN];
+        f16x8 fa[2][TM], fb[2][WQ ? 1 : TN];
+        u32x2 fq[2][WQ ? TN : 1]; // uint8 weights: the fragment's 8 codes as read, expanded right before their MFMAs
         auto lds16 = [](unsigned addr) { return *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>((uintptr_t)addr); };
+        auto lds8 = [](unsigned addr) { return *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>((uintptr_t)addr); };
         // fragments of (tap t, K half ks) of the slab in ring slot `slot` -> register set b
         auto read_half = [&](auto b_c, auto t_c, auto ks_c, int slot) {
             constexpr int b = decltype(b_c)::value, t = decltype(t_c)::value, ks = decltype(ks_c)::value;
             if (dbg & 256) return;
-            const unsigned sb = (b_addr0 + (unsigned)slot * (SLOT * 2)) ^ (ks << 6);
+            const unsigned sb = (b_addr0 + (unsigned)slot * (SLOT * 2)) ^ (ks << (WQ ? 5 : 6));
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[b][i] = lds16(a_addr[t][i] ^ (ks << 6));
+            if constexpr (WQ) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[b][j] = lds16(sb + j * 16 * 128);
+                for (int j = 0; j < TN; ++j) fq[b][j] = lds8(sb + j * 2048);
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[b][j] = lds16(sb + j * 16 * 128);
+            }
         };
         auto mfma_half = [&](auto b_c) {
             constexpr int b = decltype(b_c)::value;
+            if constexpr (WQ) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f16x8 w = u8x8_to_f16(fq[b][j], wq_z[j]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(w, fa[b][i], acc[i][j]);
+                }
+                return;
+            }
             if (dbg & 64) { // keep the fragment reads alive without the matrix pipe
 #pragma unroll
                 for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[b][j]));
@@ -1589,6 +1655,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
         };
 
         auto interleave_reads_with_mfmas = [] { // scheduling directive for the region since the last sched_barrier
+            if constexpr (WQ) return; // (the expansion's VALU work is left to the scheduler)
             constexpr int NRD = TM + TN, NMF = TM * TN, PAIRS = NRD < NMF ? NRD : NMF;
             __builtin_amdgcn_sched_group_barrier(0x002, TM + 2, 0); // the address arithmetic of the reads first
             static_for<PAIRS>([](auto) {
@@ -1672,6 +1739,17 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
     __syncthreads(); // all fragment reads done before the epilogue tile overwrites the ring
     STAMP(2);
 
+    if constexpr (WQ) { // acc holds sum_k A (q + offset_n), the integer codes exactly; the column's scale first
+        const float* scv = colv + 2 * BN + BN / 2 + 64;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(scv + wn * WTN + j * 16 + e_n);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] *= sc[r];
+        }
+    }
     int n_store = NT; // threads that take part in the store phase
     if (p.splits > 1 && p.fixup) {
         // ---- split-K WITHOUT a reduce launch: every slice publishes its fp32 tile write-through, the slice that arrives LAST at
@@ -1972,18 +2050,22 @@ hipError_t launch_glds(const GemmP& p, dim3 grid, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
-hipError_t launch_halo(const GemmP& p, dim3 grid, size_t smem, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int STAGES, bool WQ = false>
+hipError_t launch_halo_q(const GemmP& p, dim3 grid, size_t smem, hipStream_t st) {
     static std::atomic<unsigned long long> attr_devs{0};
     if (sdod::first_use_on_device(attr_devs)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<BM, BN, WM, WN, STAGES>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<BM, BN, WM, WN, STAGES, WQ>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
     const f16* z = zero_line();
     if (!z) return hipErrorOutOfMemory;
-    SDOD_LAUNCH((conv_halo_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(512), smem, st, p, z);
+    SDOD_LAUNCH((conv_halo_kernel<BM, BN, WM, WN, STAGES, WQ>), grid, dim3(512), smem, st, p, z);
     return hipGetLastError();
+}
+template <int BM, int BN, int WM, int WN, int STAGES>
+hipError_t launch_halo(const GemmP& p, dim3 grid, size_t smem, hipStream_t st) {
+    return p.wq ? launch_halo_q<BM, BN, WM, WN, STAGES, true>(p, grid, smem, st) : launch_halo_q<BM, BN, WM, WN, STAGES, false>(p, grid, smem, st);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -2014,7 +2096,8 @@ struct Plan {
 // Can halo tile `tile` run descriptor d?  Fills the geometry fields of *p (may be null) and the LDS bytes of the launch.
 bool halo_geometry(const sdod_gemm_desc* d, int tile, GemmP* p, size_t* smem_bytes) {
     if (tile < kFirstHaloTile || tile > kLastHaloTile) return false;
-    if (d->a_mode != SDOD_A_CONV3X3 || d->ksize == 1 || d->stride != 1 || d->wq || d->geglu || d->ln || d->bias_on_m) return false;
+    if (d->a_mode != SDOD_A_CONV3X3 || d->ksize == 1 || d->stride != 1 || d->geglu || d->ln || d->bias_on_m) return false;
+    if (d->wq && d->k_tail) return false;
     if (d->c0 <= 0 || d->c0 % 64 || d->c1 % 64 || d->h_in <= 0 || d->w_in <= 0 || d->n_img <= 0) return false;
     if (d->upsample && d->k_tail) return false;
     const int BMt = kTiles[tile].bm, BNt = kTiles[tile].bn, stages = kHaloStages[tile - kFirstHaloTile];
@@ -2050,7 +2133,8 @@ bool halo_geometry(const sdod_gemm_desc* d, int tile, GemmP* p, size_t* smem_byt
     const size_t tail = d->k_tail ? (size_t)halo_tail_stages(BMt, BNt, stages) * (BMt + BNt) * 128 : 0;
     const size_t ctile = (size_t)BMt * (BNt + 8) * sizeof(f16);
     const size_t body = std::max(std::max(halo, tail), ctile);
-    const size_t total = body + (size_t)2 * BNt * sizeof(float) + (size_t)BNt * sizeof(f16) + 256; // + the row-bias vector (whole DMA instructions)
+    const size_t total = body + (size_t)2 * BNt * sizeof(float) + (size_t)BNt * sizeof(f16) + 256 // + the row-bias vector (whole DMA instructions)
+                         + (d->wq ? (size_t)BNt * sizeof(float) + 256 : 0);                        // + the uint8 encoding's scale vector
     if (total > 160 * 1024) return false;
     if (smem_bytes) *smem_bytes = total;
     if (p) {
@@ -2074,7 +2158,8 @@ Plan make_plan(const sdod_gemm_desc* d) {
     const bool fused = d->geglu || d->k_tail || d->ln || d->wq;
     if (fused && (tile < 6 || tile > kNumTiles)) tile = 14; // fusions live in the LDS-DMA kernel family only
     if (d->geglu && (tile == 21 || tile == 22 || tile == 31 || tile == 35 || tile == 48)) tile = 14;
-    if (d->wq && !(tile == 8 || tile == 13 || tile == 23 || tile == 24 || (tile >= 27 && tile <= 31))) tile = 23; // uint8-weight variants
+    if (d->wq && !(tile == 8 || tile == 13 || tile == 23 || tile == 24 || (tile >= 27 && tile <= 31) || (tile >= kFirstHaloTile && tile <= kLastHaloTile)))
+        tile = 23; // uint8-weight variants
     if (d->wq && d->geglu && tile == 31) tile = 23;  // value/gate pairing needs an even number of 16-column blocks per wave
     if (tile <= 0 || tile > kNumTiles) {
         if (d->N <= 16) {
@@ -2331,7 +2416,8 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     SDOD_REQUIRE(d->phase >= 0 && d->phase <= 2 && (d->phase == 0 || pl.splits > 1), "phase 1/2 only apply to a split-K plan");
     hipError_t e = hipSuccess;
-    if (d->phase != 2 && d->wq)
+    const bool halo_tile = pl.tile >= kFirstHaloTile && pl.tile <= kLastHaloTile; // (takes uint8 weights itself: launch_halo)
+    if (d->phase != 2 && d->wq && !halo_tile)
     switch (pl.tile) { // the uint8-weight variants (make_plan maps every other tile onto one of these)
     case 8: e = launch_glds<64, 64, 2, 2, 4, false, true>(p, grid, st); break;
     case 13: e = launch_glds<128, 128, 2, 4, 4, false, true>(p, grid, st); break;

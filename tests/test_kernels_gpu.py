@@ -360,6 +360,42 @@ def test_conv3x3_halo_patch_tiles_with_upsampling(n, h, w, cin, cout, tile, spli
     check(out, ref, name=f'halo upconv {n}x{h}x{w} {cin}->{cout} tile{tile} split{split}')
 
 
+@pytest.mark.parametrize('split', [0, 1, 3])
+@pytest.mark.parametrize('tile', HALO_TILES)
+@pytest.mark.parametrize('case', ['plain64', 'plain16', 'images8', 'resblock', 'upsample'])
+def test_conv3x3_halo_patch_uint8_weights(case, tile, split):
+    """config 5 through the halo-patch kernel: the weight slabs stream as affine-uint8 codes (64-byte rows), the zero point is
+    folded into the fragment expansion (q + offset is an exact fp16 integer) and the per-column scale into the epilogue;
+    reference = fp32 convolution with the DEQUANTISED weights.  Two encodings inside one launch (fused parameter groups),
+    ragged N, concat + row bias + residual, nearest-2x upsampling, split-K."""
+    from sdod.amd import ops
+    g = torch.Generator().manual_seed(160)
+    n, h, w, c0, c1, cout, ups = {'plain64': (2, 64, 64, 128, 0, 320, False), 'plain16': (2, 16, 16, 256, 0, 200, False),
+                                  'images8': (3, 8, 8, 128, 0, 80, False), 'resblock': (2, 16, 16, 128, 64, 192, False),
+                                  'upsample': (2, 16, 16, 192, 0, 128, True)}[case]
+    cin = c0 + c1
+    q = torch.randint(0, 256, (cout, 9 * cin), generator=g, dtype=torch.uint8)
+    first = torch.arange(cout) < cout // 2
+    scale = ((torch.rand(cout, generator=g) * 0.5 + 0.75) * 2.0 / 255 * (9 * cin) ** -0.5) * torch.where(first, 1.0, 1.7)
+    offset = torch.where(first, torch.tensor(-128.0), torch.tensor(-77.0))
+    wf = (q.float() + offset[:, None]) * scale[:, None]
+    x0 = rnd((n, h, w, c0), 161)
+    x1 = rnd((n, h, w, c1), 162) if c1 else None
+    bias = torch.randn(cout, generator=g)
+    x = torch.cat([x0, x1], -1) if c1 else x0
+    ref = conv_ref(x, wf, bias, 1, ups)
+    d = dev()
+    kw = dict(conv=dict(stride=1, upsample=True) if ups else dict(stride=1), w_scale=scale.float().to(d), w_off=(offset + 128).float().to(d),
+              tile=tile, split_k=split)
+    if case == 'resblock':
+        rb = torch.randn(n, cout, generator=g).half()
+        res = rnd((n, h, w, cout), 163)
+        ref = (ref + rb.float()[:, None, None, :]).half().float() + res.float()
+        kw.update(a2=x1.to(d), row_bias=rb.to(d), rows_per_img=h * w, residual=res.to(d))
+    out = _halo_gemm(ops, x0.to(d), q.to(d), bias.to(d), **kw)
+    check(out, ref, name=f'halo conv uint8 {case} tile{tile} split{split}')
+
+
 def test_halo_tiles_reject_what_they_cannot_run():
     from sdod.amd import ops
     d = dev()

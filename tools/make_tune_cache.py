@@ -6,7 +6,7 @@ Builds every graph of the configurations the benches and the GPU tests use with 
 (engine.hip: emit_gemm) and its pick appended.  Copy the result over tune/gfx950.tune and commit it: from then on
 every process builds the same launch lists without timing anything.
 
-usage (GPU box):  python tools/make_tune_cache.py gpurun_out/gfx950.tune [--quick]
+usage (GPU box):  python tools/make_tune_cache.py gpurun_out/gfx950.tune [--quick | --only-quant]
 NEVER run under a profiler (timing noise would be baked into the picks)."""
 import os
 import sys
@@ -17,9 +17,17 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'stable-diffusio
 
 out = os.path.abspath(sys.argv[1])
 quick = '--quick' in sys.argv
+only_quant = '--only-quant' in sys.argv   # keep the shipped picks of every fp16 shape, re-time the uint8-weight shapes only
 if os.path.exists(out):
     os.remove(out)
 os.makedirs(os.path.dirname(out), exist_ok=True)
+if only_quant:
+    shipped = os.path.join(ROOT, 'stable-diffusion-on-device_amd', 'tune', 'gfx950.tune')
+    with open(shipped) as f, open(out, 'w') as g:
+        for line in f:
+            v = line.split()
+            if len(v) == 13 and not (int(v[10]) & (1 << 29)):   # key field 10, bit 29 = uint8 weights (engine.hip: key_of)
+                g.write(line)
 os.environ['SDOD_TUNE_CACHE'] = out
 os.environ['SDOD_TUNE_DEFAULT'] = '0'
 
@@ -39,6 +47,16 @@ def build(cls, cfg, batch, seed, label, quant=False):
     print(f'[{time.time() - T0:6.1f}s] {label}: {g.stats()["launches"]} launches; table now {n} shapes', flush=True)
     del g
 
+
+if only_quant:
+    for hw in (96, 24):
+        cq = E.sd21_config(hw, hw)
+        cq.weight_quant = 1
+        build(E.UNet, cq, 2, 2100, f'sd21 unet {hw}x{hw} b2, uint8 weights', quant=True)
+        build(E.Temb, cq, 1, 2101, 'sd21 temb b1, uint8 weights', quant=True)
+        build(E.Temb, cq, 20, 2101, 'sd21 temb b20, uint8 weights', quant=True)
+    print(f'done: {out}')
+    sys.exit(0)
 
 # headline (configs 2/3), config 4's per-rank share (batch 4), latency mode (batch 1)
 c64 = E.sd14_config(64, 64)
