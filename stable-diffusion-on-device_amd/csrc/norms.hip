@@ -1174,56 +1174,73 @@ void gn_launch(GnP& p, hipStream_t st) {
 
 constexpr int GN_MAX_CHUNKS = 1024;
 
-// ---------------------------------------------------------------- LayerNorm: one wave per row
+// ---------------------------------------------------------------- LayerNorm: LPR lanes per row, 64 / LPR rows per wave
+// A row of C = 320 .. 1280 channels is 40 .. 160 16-byte chunks: with a whole wave per row most lanes idle and every row pays
+// two full-wave shuffle reductions (27 us for 18432 x 320: 0.87 TB/s).  Here LPR = 8 / 16 / 32 / 64 lanes share a row (at most
+// KC = 6 chunks per lane, all loads of a row in flight at once), the reductions stay inside the lane group, and the affine
+// parameters sit in LDS (8 bytes per channel, loaded once per workgroup).  Exact two-pass statistics on the registers, as before.
+template <int LPR>
 __global__ __launch_bounds__(256) void layer_norm_kernel(const f16* x, f16* y, const float* w, const float* b, int M,
                                                          int C, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    constexpr int KC = 6, RPW = 64 / LPR;
+    extern __shared__ __attribute__((aligned(16))) float ln_par[]; // [C] weight, [C] bias
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, j = lane % LPR;
     const int cp = C / 8;
-    const f16* xr = x + (size_t)row * C;
-    f16x8 v[4];
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < cp) {
-            v[i] = ldg8(xr + ch * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sum += (float)v[i][e];
-        }
+    for (int i = threadIdx.x; i < C; i += 256) {
+        ln_par[i] = w ? w[i] : 1.0f;
+        ln_par[C + i] = b ? b[i] : 0.0f;
     }
+    __syncthreads();
+    const float inv_c = 1.0f / (float)C;
+    const int rows_per_pass = gridDim.x * 4 * RPW;
+    for (int row0 = (blockIdx.x * 4 + wave) * RPW; row0 < M; row0 += rows_per_pass) { // wave-uniform trip count (the shuffles)
+        const int row = row0 + sub;
+        const bool ok = row < M;
+        const f16* xr = x + (size_t)(ok ? row : 0) * C;
+        f16x8 v[KC];
+        float sum = 0.f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    const float mean = sum / (float)C;
-    float sq = 0.f;
+        for (int k = 0; k < KC; ++k) {
+            const int ch = j + LPR * k;
+            v[k] = (ok && ch < cp) ? ldg8(xr + ch * 8) : zero8();
+        }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < cp) {
+        for (int k = 0; k < KC; ++k)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float d = (float)v[i][e] - mean;
-                sq += d * d;
+            for (int e = 0; e < 8; ++e) sum += (float)v[k][e];
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum * inv_c;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            if (j + LPR * k < cp) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = (float)v[k][e] - mean;
+                    sq += d * d;
+                }
             }
         }
-    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-    const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
-    f16* yr = y + (size_t)row * C;
+        for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        const float rstd = 1.0f / sqrtf(sq * inv_c + eps);
+        f16* yr = y + (size_t)(ok ? row : 0) * C;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < cp) {
-            f16x8 o;
+        for (int k = 0; k < KC; ++k) {
+            const int ch = j + LPR * k;
+            if (ok && ch < cp) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(ln_par + ch * 8), w1 = *reinterpret_cast<const f32x4*>(ln_par + ch * 8 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(ln_par + C + ch * 8), b1 = *reinterpret_cast<const f32x4*>(ln_par + C + ch * 8 + 4);
+                f16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = ch * 8 + e;
-                const float ww = w ? w[c] : 1.0f, bb = b ? b[c] : 0.0f;
-                o[e] = (f16)(((float)v[i][e] - mean) * rstd * ww + bb);
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (f16)(((float)v[k][e] - mean) * rstd * w0[e] + b0[e]);
+                    o[e + 4] = (f16)(((float)v[k][e + 4] - mean) * rstd * w1[e] + b1[e]);
+                }
+                stg8(yr + ch * 8, o);
             }
-            stg8(yr + ch * 8, o);
         }
     }
 }
@@ -1367,9 +1384,21 @@ extern "C" int sdod_layer_norm_f16(const void* x, void* y, const float* weight, 
                                    void* stream) {
     SDOD_TRY
     SDOD_REQUIRE(x && y, "null pointer");
-    SDOD_REQUIRE(m > 0 && c > 0 && c % 8 == 0 && c <= 2048, "LayerNorm needs C % 8 == 0 and C <= 2048");
-    SDOD_LAUNCH(layer_norm_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y,
-                       weight, bias, m, c, eps);
+    SDOD_REQUIRE(m > 0 && c > 0 && c % 8 == 0 && c <= 3072, "LayerNorm needs C % 8 == 0 and C <= 3072");
+    const int cp = c / 8;
+    const int lpr = cp <= 48 ? 8 : cp <= 96 ? 16 : cp <= 192 ? 32 : 64; // lanes per row: at most 6 chunks per lane
+    const int rows_per_wg = 4 * (64 / lpr);
+    const int grid = std::min((m + rows_per_wg - 1) / rows_per_wg, 2048);
+    const size_t lds = (size_t)2 * c * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    const f16* xs = (const f16*)x;
+    f16* yd = (f16*)y;
+    switch (lpr) {
+    case 8: SDOD_LAUNCH(layer_norm_kernel<8>, dim3(grid), dim3(256), lds, st, xs, yd, weight, bias, m, c, eps); break;
+    case 16: SDOD_LAUNCH(layer_norm_kernel<16>, dim3(grid), dim3(256), lds, st, xs, yd, weight, bias, m, c, eps); break;
+    case 32: SDOD_LAUNCH(layer_norm_kernel<32>, dim3(grid), dim3(256), lds, st, xs, yd, weight, bias, m, c, eps); break;
+    default: SDOD_LAUNCH(layer_norm_kernel<64>, dim3(grid), dim3(256), lds, st, xs, yd, weight, bias, m, c, eps); break;
+    }
     SDOD_HIP_CHECK(hipGetLastError());
     return 0;
     SDOD_CATCH

@@ -563,7 +563,10 @@ def test_efficient_gn_module_matches_reference_golden(golden_dir):
 
 def test_layer_norm():
     from sdod.amd import ops
-    for m, c in ((8192, 320), (2048, 640), (512, 1280), (154, 768)):
+    # 8 / 16 / 32 / 64 lanes per row (norms.hip: layer_norm_kernel<LPR>), row counts that do not fill the last wave, more rows
+    # than one pass of the grid covers, widths that do not fill the lane groups
+    for m, c in ((8192, 320), (2048, 640), (512, 1280), (154, 768), (18432, 320), (77, 1024), (3, 64), (1, 8), (1031, 328),
+                 (70000, 320), (45, 2048), (9, 3072)):
         gen = torch.Generator().manual_seed(60)
         x = (torch.randn(m, c, generator=gen) + 0.5).half()
         wt = 1 + 0.1 * torch.randn(c, generator=gen); b = 0.1 * torch.randn(c, generator=gen)

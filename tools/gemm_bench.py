@@ -48,6 +48,7 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--split', type=int, default=0, help='force split-K factor (0 = auto)')
     ap.add_argument('--lib', default='', help='load lib/<name> instead of libsdod.so (ablation builds, see the Makefile)')
+    ap.add_argument('--u8', action='store_true', help='affine-uint8 weight codes (config 5): the kernels stream bytes and expand on the fragment read')
     ap.add_argument('--cold', action='store_true', help='sweep the caches before every timed launch (weights from HBM)')
     args = ap.parse_args()
     if args.lib:
@@ -59,24 +60,30 @@ def main():
     g = torch.Generator(device='cpu').manual_seed(0)
     scratch = torch.zeros(512 << 20, dtype=torch.uint8, device=d) if args.cold else None
     print(f'{"shape":28s} {"GFLOP":>8s} ' + ' '.join(f'{"t" + str(t) + " us":>9s} {"TF/s":>7s}' for t in tiles), flush=True)
+    def weights(n, k):
+        if not args.u8:
+            return (torch.randn(n, k, generator=g) * k ** -0.5).half().to(d), {}
+        q = torch.randint(0, 256, (n, k), generator=g, dtype=torch.uint8).to(d)
+        return q, dict(w_scale=torch.full((n,), 2.0 / 255 * k ** -0.5).to(d), w_off=torch.zeros(n).to(d))
+
     for name, kind, prm in SHAPES:
         if args.only and args.only not in name:
             continue
         if kind == 'rows':
             m, n, k = prm
             a = torch.randn(m, k, generator=g).half().to(d)
-            w = (torch.randn(n, k, generator=g) * k ** -0.5).half().to(d)
+            w, wkw = weights(n, k)
             bias = torch.randn(n).to(d)
             fl = 2.0 * m * n * k
-            call = lambda t, it=0: ops.gemm(a, w, bias, tile=t, time_iters=it, split_k=args.split, cold_scratch=scratch)
+            call = lambda t, it=0: ops.gemm(a, w, bias, tile=t, time_iters=it, split_k=args.split, cold_scratch=scratch, **wkw)
         else:
             nb, h, wd, cin, cout, stride, ups = prm
             a = torch.randn(nb, h, wd, cin, generator=g).half().to(d)
-            w = (torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5).half().to(d)
+            w, wkw = weights(cout, 9 * cin)
             bias = torch.randn(cout).to(d)
             ho = (h * (2 if ups else 1)) // stride
             fl = 2.0 * nb * ho * ho * cout * 9 * cin
-            call = lambda t, it=0: ops.gemm(a, w, bias, conv=dict(stride=stride, upsample=ups), tile=t, time_iters=it, split_k=args.split, cold_scratch=scratch)
+            call = lambda t, it=0: ops.gemm(a, w, bias, conv=dict(stride=stride, upsample=ups), tile=t, time_iters=it, split_k=args.split, cold_scratch=scratch, **wkw)
         row = f'{name:28s} {fl / 1e9:8.2f} '
         for t in tiles:
             try:
