@@ -485,7 +485,8 @@ namespace {
 constexpr size_t kPrefetchMinBytes = (size_t)12 << 20; // weight matrices at least this big are prefetched (Graph::run_ops)
 const int kCandidates[] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, // (25, 26 spill in their epilogue only; the tuner decides)
                            37, 38, 39, 40, 41, 42, 43, 44, 45, // halo-patch convolution tiles: rejected by every other descriptor
-                           46, 47, 48};
+                           46, 47, 48,
+                           49, 50, 51, 52}; // halo-patch tiles of 96 / 192 rows (image rows that are multiples of 3: config 5)
 
 struct ShapeKey {
     int v[12];

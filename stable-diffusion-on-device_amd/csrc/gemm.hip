@@ -453,11 +453,8 @@ SDOD_DEVICE f16x8 u8x8_to_f16(u32x2 d, f16 z) {
     w[3] = __builtin_amdgcn_perm(c64, d[1], 0x04030402u);
     u32x4v o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { // v_pk_add_f16, spelled out: the vector form of the subtraction is scalarised when z is a register
-        uint32_t r;
-        asm("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(w[i]), "v"(nz));
-        o[i] = r;
-    }
+    for (int i = 0; i < 4; ++i) // two-wide vector adds: v_pk_add_f16 (the 8-wide subtraction of a splat is scalarised when z is a register)
+        o[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, w[i]) + nz);
     return __builtin_bit_cast(f16x8, o);
 }
 // fragment of weight row `row` (tile-local), K half `ks`, lane chunk `fc` (0..3), from the uint8 slab image (8-row groups at a
@@ -1223,6 +1220,9 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
 #endif
 }
 
+// patch DMA rounds (256 lanes x 16 bytes each) a halo tile of bm output rows can need: (rows + 2) x (width + 2) pixels of 128
+// bytes.  96- and 192-row tiles exist for images whose rows are multiples of 3 (SD v2.1-768: 96 / 48 / 24 / 12 pixels)
+constexpr int halo_nrmax(int bm) { return bm <= 64 ? 7 : bm == 96 ? 10 : bm <= 128 ? 9 : 13; }
 // ring depth of conv_halo_kernel's tail program: its slots hold A next to B, so fewer of them fit
 constexpr int halo_tail_stages(int bm, int bn, int stages) {
     const int fit = (150 * 1024) / ((bm + bn) * 128);
@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
     constexpr int B_LDX = (BG + NL - 1) / NL;   // ... per loader wave, at most
     constexpr int A_LD = BM / (8 * NL);         // tail program: A groups per loader wave
     constexpr int SC = BN + 8;
-    constexpr int NRMAX = BM <= 64 ? 7 : BM <= 128 ? 9 : 13; // patch DMA rounds (256 lanes x 16 bytes each) this tile can need
+    constexpr int NRMAX = halo_nrmax(BM); // patch DMA rounds this tile can need
     constexpr int AHEAD = STAGES - 1;
 #ifdef SDOD_GEMM_ABLATE
     constexpr int dbg = SDOD_GEMM_ABLATE; // developer builds: 16 no patch DMA inside the loop, 32 no weight DMA inside the loop, 64 no MFMA,
@@ -2011,11 +2011,15 @@ const TileCfg kTiles[] = {{0, 0},     {128, 128}, {128, 64}, {64, 64},   {256, 1
                           {64, 160}, {128, 80}, {128, 160}, {64, 80}, {256, 32}, {128, 32}, {256, 64}, {128, 64}, {64, 64},
                           // 46..48: wave-specialised 32-row tiles for the small-M Linear layers (M = 512 at the 16x16 level: twice the
                           // workgroups of a 64-row tile at three quarters of its bytes per slab)
-                          {32, 64}, {32, 128}, {32, 160}};
-constexpr int kNumTiles = 48;
-constexpr int kFirstHaloTile = 37, kLastHaloTile = 45;
+                          {32, 64}, {32, 128}, {32, 160},
+                          // 49..52: halo-patch tiles of 96 / 192 rows, for images whose rows are multiples of 3 (config 5: 96 / 48 / 24 / 12)
+                          {96, 160}, {96, 64}, {192, 80}, {192, 64}};
+constexpr int kNumTiles = 52;
+constexpr int kFirstHaloTile = 37, kLastHaloTile = 45, kFirstHaloTile3 = 49, kLastHaloTile3 = 52;
+constexpr bool is_halo_tile(int t) { return (t >= kFirstHaloTile && t <= kLastHaloTile) || (t >= kFirstHaloTile3 && t <= kLastHaloTile3); }
 // {STAGES} of the halo tiles (WM x WN is 2x2 for the 160- and 64-wide square-ish ones, 4x1 for the tall ones: launch switch)
-const int kHaloStages[] = {4, 4, 3, 4, 6, 6, 4, 4, 4};
+const int kHaloStages[] = {4, 4, 3, 4, 6, 6, 4, 4, 4, /* 49.. */ 3, 4, 4, 4};
+constexpr int halo_index(int t) { return t <= kLastHaloTile ? t - kFirstHaloTile : t - kFirstHaloTile3 + (kLastHaloTile - kFirstHaloTile + 1); }
 
 const f16* zero_line() { // one per device (the pointer is only valid on the device that allocated it)
     static std::atomic<f16*> z[64];
@@ -2095,12 +2099,12 @@ struct Plan {
 
 // Can halo tile `tile` run descriptor d?  Fills the geometry fields of *p (may be null) and the LDS bytes of the launch.
 bool halo_geometry(const sdod_gemm_desc* d, int tile, GemmP* p, size_t* smem_bytes) {
-    if (tile < kFirstHaloTile || tile > kLastHaloTile) return false;
+    if (!is_halo_tile(tile)) return false;
     if (d->a_mode != SDOD_A_CONV3X3 || d->ksize == 1 || d->stride != 1 || d->geglu || d->ln || d->bias_on_m) return false;
     if (d->wq && d->k_tail) return false;
     if (d->c0 <= 0 || d->c0 % 64 || d->c1 % 64 || d->h_in <= 0 || d->w_in <= 0 || d->n_img <= 0) return false;
     if (d->upsample && d->k_tail) return false;
-    const int BMt = kTiles[tile].bm, BNt = kTiles[tile].bn, stages = kHaloStages[tile - kFirstHaloTile];
+    const int BMt = kTiles[tile].bm, BNt = kTiles[tile].bn, stages = kHaloStages[halo_index(tile)];
     const int ups = d->upsample ? 1 : 0;
     const int H = d->h_in << ups, W = d->w_in << ups; // OUTPUT size: the tile lives there, the patch in the (smaller) source
     int tw, th, parts;
@@ -2124,7 +2128,7 @@ bool halo_geometry(const sdod_gemm_desc* d, int tile, GemmP* p, size_t* smem_byt
     if (ups && ((th > 1 && (th & 1)) || (tw & 1))) return false;
     const int pw = (ups ? tw / 2 : tw) + 2, ppix = ((ups ? th / 2 : th) + 2) * pw, npix = parts * ppix;
     const int nr = (npix * 8 + 255) / 256;
-    const int nrmax = BMt <= 64 ? 7 : BMt <= 128 ? 9 : 13;
+    const int nrmax = halo_nrmax(BMt);
     if (nr > nrmax) return false;
     const long long maxc = std::max(std::max(d->c0, d->c1), std::max(d->tc0, d->tc1));
     if ((long long)d->n_img * H * W * maxc >= (1ll << 31)) return false;
@@ -2158,7 +2162,7 @@ Plan make_plan(const sdod_gemm_desc* d) {
     const bool fused = d->geglu || d->k_tail || d->ln || d->wq;
     if (fused && (tile < 6 || tile > kNumTiles)) tile = 14; // fusions live in the LDS-DMA kernel family only
     if (d->geglu && (tile == 21 || tile == 22 || tile == 31 || tile == 35 || tile == 48)) tile = 14;
-    if (d->wq && !(tile == 8 || tile == 13 || tile == 23 || tile == 24 || (tile >= 27 && tile <= 31) || (tile >= kFirstHaloTile && tile <= kLastHaloTile)))
+    if (d->wq && !(tile == 8 || tile == 13 || tile == 23 || tile == 24 || (tile >= 27 && tile <= 31) || is_halo_tile(tile)))
         tile = 23; // uint8-weight variants
     if (d->wq && d->geglu && tile == 31) tile = 23;  // value/gate pairing needs an even number of 16-column blocks per wave
     if (tile <= 0 || tile > kNumTiles) {
@@ -2187,7 +2191,7 @@ Plan make_plan(const sdod_gemm_desc* d) {
         }
     }
     pl.main_splits = 0;
-    if (tile >= kFirstHaloTile && tile <= kLastHaloTile && halo_geometry(d, tile, nullptr, nullptr)) { // (a descriptor it cannot run is rejected at launch)
+    if (is_halo_tile(tile) && halo_geometry(d, tile, nullptr, nullptr)) { // (a descriptor it cannot run is rejected at launch)
         // whole 64-channel chunks (9 tap slabs) per split; the 1x1 tail, if any, is one more slice
         const int nmain = (d->c0 + d->c1) / BK;
         int want = d->split_k;
@@ -2215,7 +2219,7 @@ Plan make_plan(const sdod_gemm_desc* d) {
 namespace {
 constexpr size_t kFixupCounters = (size_t)64 << 10;
 bool fixup_applies(const sdod_gemm_desc* d, const Plan& pl) {
-    if (!d->fix_counters || d->phase != 0 || pl.splits <= 1 || pl.tile < kFirstHaloTile || pl.tile > kLastHaloTile || d->N % 4 != 0) return false;
+    if (!d->fix_counters || d->phase != 0 || pl.splits <= 1 || !is_halo_tile(pl.tile) || d->N % 4 != 0) return false;
     const size_t tiles = (size_t)((d->M + kTiles[pl.tile].bm - 1) / kTiles[pl.tile].bm) * ((d->N + kTiles[pl.tile].bn - 1) / kTiles[pl.tile].bn);
     return tiles <= kFixupCounters && halo_geometry(d, pl.tile, nullptr, nullptr);
 }
@@ -2287,7 +2291,8 @@ extern "C" int sdod_gemm_tile_info(int tile, int out[7]) {
         // SPEC column 2 = conv_halo_kernel<BM, BN, WM, WN, STAGES>
         {64, 160, 2, 2, 4, 2, 1}, {128, 80, 4, 1, 4, 2, 1}, {128, 160, 2, 2, 3, 2, 1}, {64, 80, 4, 1, 4, 2, 1}, {256, 32, 4, 1, 6, 2, 1},
         {128, 32, 4, 1, 6, 2, 1}, {256, 64, 4, 1, 4, 2, 1}, {128, 64, 2, 2, 4, 2, 1}, {64, 64, 2, 2, 4, 2, 1},
-        {32, 64, 2, 2, 6, 1, 1}, {32, 128, 1, 4, 6, 1, 1}, {32, 160, 2, 2, 4, 1, 1}};
+        {32, 64, 2, 2, 6, 1, 1}, {32, 128, 1, 4, 6, 1, 1}, {32, 160, 2, 2, 4, 1, 1},
+        {96, 160, 2, 2, 3, 2, 1}, {96, 64, 2, 2, 4, 2, 1}, {192, 80, 4, 1, 4, 2, 1}, {192, 64, 4, 1, 4, 2, 1}};
     static_assert(sizeof(kInfo) / sizeof(kInfo[0]) == kNumTiles + 1, "one row per tile");
     if (tile < 1 || tile > kNumTiles || !out) return sdod::INVALID_ARGUMENT;
     for (int i = 0; i < 7; ++i) out[i] = kInfo[tile][i];
@@ -2392,7 +2397,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     p.splits = pl.splits;
     p.kt_per_split = pl.kt_per_split;
     size_t halo_smem = 0;
-    if (pl.tile >= kFirstHaloTile && pl.tile <= kLastHaloTile) {
+    if (is_halo_tile(pl.tile)) {
         SDOD_REQUIRE(halo_geometry(d, pl.tile, &p, &halo_smem), "this halo-patch tile does not take the convolution (3x3, stride 1, tile rows must divide the image)");
         p.h_main_splits = pl.main_splits;
         if (fixup_applies(d, pl)) {
@@ -2416,7 +2421,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     SDOD_REQUIRE(d->phase >= 0 && d->phase <= 2 && (d->phase == 0 || pl.splits > 1), "phase 1/2 only apply to a split-K plan");
     hipError_t e = hipSuccess;
-    const bool halo_tile = pl.tile >= kFirstHaloTile && pl.tile <= kLastHaloTile; // (takes uint8 weights itself: launch_halo)
+    const bool halo_tile = is_halo_tile(pl.tile); // (takes uint8 weights itself: launch_halo)
     if (d->phase != 2 && d->wq && !halo_tile)
     switch (pl.tile) { // the uint8-weight variants (make_plan maps every other tile onto one of these)
     case 8: e = launch_glds<64, 64, 2, 2, 4, false, true>(p, grid, st); break;
@@ -2440,6 +2445,10 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     case 43: e = launch_halo<256, 64, 4, 1, 4>(p, grid, halo_smem, st); break;
     case 44: e = launch_halo<128, 64, 2, 2, 4>(p, grid, halo_smem, st); break;
     case 45: e = launch_halo<64, 64, 2, 2, 4>(p, grid, halo_smem, st); break;
+    case 49: e = launch_halo<96, 160, 2, 2, 3>(p, grid, halo_smem, st); break;
+    case 50: e = launch_halo<96, 64, 2, 2, 4>(p, grid, halo_smem, st); break;
+    case 51: e = launch_halo<192, 80, 4, 1, 4>(p, grid, halo_smem, st); break;
+    case 52: e = launch_halo<192, 64, 4, 1, 4>(p, grid, halo_smem, st); break;
     case 1: e = launch_cfg<128, 128, 2, 2>(p, grid, st); break;
     case 2: e = launch_cfg<128, 64, 2, 2>(p, grid, st); break;
     case 3: e = launch_cfg<64, 64, 2, 2>(p, grid, st); break;

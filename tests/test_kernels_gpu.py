@@ -276,7 +276,7 @@ def test_conv3x3_with_skip_tail_segment(tile):
     check(out, ref, name=f'conv + skip tail tile{tile}')
 
 
-HALO_TILES = list(range(37, 46))
+HALO_TILES = list(range(37, 46)) + [49, 50, 51, 52]   # 49..52: 96- / 192-row tiles (image rows that are multiples of 3: config 5)
 
 
 def _halo_gemm(ops, *args, **kw):
@@ -294,6 +294,8 @@ def _halo_gemm(ops, *args, **kw):
 @pytest.mark.parametrize('n,h,w,cin,cout', [
     (2, 64, 64, 128, 320), (2, 32, 32, 192, 160), (2, 16, 16, 256, 256), (2, 8, 8, 320, 192), (1, 8, 8, 64, 64),
     (3, 8, 8, 128, 80), (1, 128, 128, 64, 128), (5, 16, 16, 64, 48),
+    # SD v2.1-768 geometry (rows that are multiples of 3): only the 96- / 192-row tiles take these
+    (2, 96, 96, 64, 160), (2, 48, 48, 128, 80), (2, 24, 24, 192, 128), (1, 12, 12, 64, 200), (3, 12, 12, 128, 64),
 ])
 def test_conv3x3_halo_patch_tiles(n, h, w, cin, cout, tile, split):
     """conv_halo_kernel (input patch resident in LDS, K walked chunk-major / tap-minor) against the fp32 convolution:
@@ -302,9 +304,9 @@ def test_conv3x3_halo_patch_tiles(n, h, w, cin, cout, tile, split):
     from sdod.amd import ops
     x = rnd((n, h, w, cin), 120); wt = rnd((cout, 9 * cin), 121, (9 * cin) ** -0.5)
     bias = torch.randn(cout, generator=torch.Generator().manual_seed(122))
-    ref = conv_ref(x, wt, bias)
     d = dev()
     out = _halo_gemm(ops, x.to(d), wt.to(d), bias.to(d), conv=dict(stride=1), tile=tile, split_k=split)
+    ref = conv_ref(x, wt, bias)
     check(out, ref, name=f'halo conv {n}x{h}x{w} {cin}->{cout} tile{tile} split{split}')
     # opt-in: a split-K plan reduced INSIDE the GEMM launch (last K slice to arrive at the tile's counter reduces; fix_counters in
     # include/sdod_hip.h) -- the same sum in the same order as splitk_reduce_kernel, so the same bits, also on a second launch
@@ -316,11 +318,12 @@ def test_conv3x3_halo_patch_tiles(n, h, w, cin, cout, tile, split):
 
 @pytest.mark.parametrize('split', [1, 2])
 @pytest.mark.parametrize('tile', HALO_TILES)
-def test_conv3x3_halo_concat_rowbias_residual_tail(tile, split):
+@pytest.mark.parametrize('hw', [16, 24])
+def test_conv3x3_halo_concat_rowbias_residual_tail(hw, tile, split):
     """everything a ResBlock asks of one launch: two-source channel concat, time-embedding row bias, SiLU-less epilogue with
-    residual, and the fused 1x1 skip connection as the extra split-K slice"""
+    residual, and the fused 1x1 skip connection as the extra split-K slice (24 x 24: the 96- / 192-row tiles)"""
     from sdod.amd import ops
-    n, h, w, c0, c1, cout = 2, 16, 16, 128, 64, 192
+    n, h, w, c0, c1, cout = 2, hw, hw, 128, 64, 192
     x0 = rnd((n, h, w, c0), 130); x1 = rnd((n, h, w, c1), 131)
     wt = rnd((cout, 9 * (c0 + c1)), 132, (9 * (c0 + c1)) ** -0.5)
     bias = torch.randn(cout, generator=torch.Generator().manual_seed(133))
@@ -347,22 +350,23 @@ def test_conv3x3_halo_concat_rowbias_residual_tail(tile, split):
 
 @pytest.mark.parametrize('split', [0, 2])
 @pytest.mark.parametrize('tile', HALO_TILES)
-@pytest.mark.parametrize('n,h,w,cin,cout', [(2, 32, 32, 128, 160), (2, 16, 16, 192, 128), (1, 8, 8, 128, 128), (3, 4, 4, 64, 80), (1, 64, 64, 64, 64)])
+@pytest.mark.parametrize('n,h,w,cin,cout', [(2, 32, 32, 128, 160), (2, 16, 16, 192, 128), (1, 8, 8, 128, 128), (3, 4, 4, 64, 80), (1, 64, 64, 64, 64),
+                                            (2, 48, 48, 64, 80), (2, 12, 12, 128, 128), (1, 24, 24, 64, 64)])
 def test_conv3x3_halo_patch_tiles_with_upsampling(n, h, w, cin, cout, tile, split):
     """Upsample.conv: nearest-2x folded into the halo-patch kernel -- the patch is cut from the low-resolution source and the
     per-tap fragment addresses map output (y, x) onto source (y >> 1, x >> 1)"""
     from sdod.amd import ops
     x = rnd((n, h, w, cin), 150); wt = rnd((cout, 9 * cin), 151, (9 * cin) ** -0.5)
     bias = torch.randn(cout, generator=torch.Generator().manual_seed(152))
-    ref = conv_ref(x, wt, bias, 1, True)
     d = dev()
     out = _halo_gemm(ops, x.to(d), wt.to(d), bias.to(d), conv=dict(stride=1, upsample=True), tile=tile, split_k=split)
+    ref = conv_ref(x, wt, bias, 1, True)
     check(out, ref, name=f'halo upconv {n}x{h}x{w} {cin}->{cout} tile{tile} split{split}')
 
 
 @pytest.mark.parametrize('split', [0, 1, 3])
 @pytest.mark.parametrize('tile', HALO_TILES)
-@pytest.mark.parametrize('case', ['plain64', 'plain16', 'images8', 'resblock', 'upsample'])
+@pytest.mark.parametrize('case', ['plain64', 'plain16', 'images8', 'resblock', 'upsample', 'rows48', 'resblock24'])
 def test_conv3x3_halo_patch_uint8_weights(case, tile, split):
     """config 5 through the halo-patch kernel: the weight slabs stream as affine-uint8 codes (64-byte rows), the zero point is
     folded into the fragment expansion (q + offset is an exact fp16 integer) and the per-column scale into the epilogue;
@@ -372,7 +376,8 @@ def test_conv3x3_halo_patch_uint8_weights(case, tile, split):
     g = torch.Generator().manual_seed(160)
     n, h, w, c0, c1, cout, ups = {'plain64': (2, 64, 64, 128, 0, 320, False), 'plain16': (2, 16, 16, 256, 0, 200, False),
                                   'images8': (3, 8, 8, 128, 0, 80, False), 'resblock': (2, 16, 16, 128, 64, 192, False),
-                                  'upsample': (2, 16, 16, 192, 0, 128, True)}[case]
+                                  'upsample': (2, 16, 16, 192, 0, 128, True), 'rows48': (2, 48, 48, 128, 0, 200, False),
+                                  'resblock24': (2, 24, 24, 128, 64, 192, False)}[case]
     cin = c0 + c1
     q = torch.randint(0, 256, (cout, 9 * cin), generator=g, dtype=torch.uint8)
     first = torch.arange(cout) < cout // 2
@@ -387,7 +392,7 @@ def test_conv3x3_halo_patch_uint8_weights(case, tile, split):
     d = dev()
     kw = dict(conv=dict(stride=1, upsample=True) if ups else dict(stride=1), w_scale=scale.float().to(d), w_off=(offset + 128).float().to(d),
               tile=tile, split_k=split)
-    if case == 'resblock':
+    if case.startswith('resblock'):
         rb = torch.randn(n, cout, generator=g).half()
         res = rnd((n, h, w, cout), 163)
         ref = (ref + rb.float()[:, None, None, :]).half().float() + res.float()

@@ -6,7 +6,7 @@ Builds every graph of the configurations the benches and the GPU tests use with 
 (engine.hip: emit_gemm) and its pick appended.  Copy the result over tune/gfx950.tune and commit it: from then on
 every process builds the same launch lists without timing anything.
 
-usage (GPU box):  python tools/make_tune_cache.py gpurun_out/gfx950.tune [--quick | --only-quant]
+usage (GPU box):  python tools/make_tune_cache.py gpurun_out/gfx950.tune [--quick | --only-quant | --only-rows3]
 NEVER run under a profiler (timing noise would be baked into the picks)."""
 import os
 import sys
@@ -18,15 +18,20 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'stable-diffusio
 out = os.path.abspath(sys.argv[1])
 quick = '--quick' in sys.argv
 only_quant = '--only-quant' in sys.argv   # keep the shipped picks of every fp16 shape, re-time the uint8-weight shapes only
+only_rows3 = '--only-rows3' in sys.argv   # re-time only the 3x3 stride-1 convolutions on images whose rows are multiples of 3 (config 5)
 if os.path.exists(out):
     os.remove(out)
 os.makedirs(os.path.dirname(out), exist_ok=True)
-if only_quant:
+if only_quant or only_rows3:
     shipped = os.path.join(ROOT, 'stable-diffusion-on-device_amd', 'tune', 'gfx950.tune')
     with open(shipped) as f, open(out, 'w') as g:
         for line in f:
             v = line.split()
-            if len(v) == 13 and not (int(v[10]) & (1 << 29)):   # key field 10, bit 29 = uint8 weights (engine.hip: key_of)
+            if len(v) != 13:
+                continue
+            # key fields (engine.hip: key_of): 0 a_mode, 6 stride, 8 ksize, 9 h_in, 10 flags (bit 29 = uint8 weights)
+            drop = (int(v[10]) & (1 << 29)) if only_quant else (v[0] == '1' and v[6] == '1' and v[8] == '3' and int(v[9]) % 3 == 0)
+            if not drop:
                 g.write(line)
 os.environ['SDOD_TUNE_CACHE'] = out
 os.environ['SDOD_TUNE_DEFAULT'] = '0'
@@ -55,6 +60,18 @@ if only_quant:
         build(E.UNet, cq, 2, 2100, f'sd21 unet {hw}x{hw} b2, uint8 weights', quant=True)
         build(E.Temb, cq, 1, 2101, 'sd21 temb b1, uint8 weights', quant=True)
         build(E.Temb, cq, 20, 2101, 'sd21 temb b20, uint8 weights', quant=True)
+    print(f'done: {out}')
+    sys.exit(0)
+
+if only_rows3:
+    c96 = E.sd21_config(96, 96)
+    build(E.UNet, c96, 2, 2100, 'sd21 unet 96x96 b2')
+    for hw in (96, 24):
+        cq = E.sd21_config(hw, hw)
+        cq.weight_quant = 1
+        build(E.UNet, cq, 2, 2100, f'sd21 unet {hw}x{hw} b2, uint8 weights', quant=True)
+    build(E.VaeDecoder, c96, 1, 1236, 'vae 96x96')
+    build(E.UNet, E.sd21_config(24, 24), 2, 2100, 'sd21 unet 24x24 b2')
     print(f'done: {out}')
     sys.exit(0)
 
