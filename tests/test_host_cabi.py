@@ -176,7 +176,13 @@ def test_halo_patch_tile_planning_without_a_gpu():
     # tile metadata for profilers: SPEC column 2 marks conv_halo_kernel<BM, BN, WM, WN, STAGES>
     info = (ctypes.c_int * 7)()
     assert lib.sdod_gemm_tile_info(38, info) == 0 and list(info) == [128, 80, 4, 1, 4, 2, 1]
-    assert lib.sdod_gemm_num_tiles() >= 48
+    assert lib.sdod_gemm_num_tiles() >= 52
+    # 96- / 192-row tiles (49..52) hold images whose rows are multiples of 3 (SD v2.1-768: 96 / 48 / 24 / 12): chunk-granular
+    # plans there, the generic K split on a 64-pixel image (the launch would refuse it)
+    assert lib.sdod_gemm_tile_info(51, info) == 0 and list(info) == [192, 80, 4, 1, 4, 2, 1]
+    assert plan(_conv_desc(2, 96, 96, 320, 320, tile=52, split=8)) == (52, 5)          # 5 chunks at most
+    assert plan(_conv_desc(2, 24, 24, 1280, 1280, tile=49, split=3)) == (49, 3)        # ceil(20 / 7) chunks per slice -> 3 slices
+    assert plan(_conv_desc(2, 64, 64, 320, 320, tile=52, split=8)) == (52, 8)          # 45 slabs / 8: not chunk-granular
 
 
 def test_group_norm_path_selection_without_a_gpu():
