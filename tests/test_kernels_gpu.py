@@ -399,6 +399,8 @@ def test_conv3x3_halo_patch_uint8_weights(case, tile, split):
         kw.update(a2=x1.to(d), row_bias=rb.to(d), rows_per_img=h * w, residual=res.to(d))
     out = _halo_gemm(ops, x0.to(d), q.to(d), bias.to(d), **kw)
     check(out, ref, name=f'halo conv uint8 {case} tile{tile} split{split}')
+    if split != 1:   # the opt-in in-kernel split-K reduce sees the already scaled accumulators: same bits as the reduce kernel
+        assert torch.equal(ops.gemm(x0.to(d), q.to(d), bias.to(d), fixup=True, **kw), out)
 
 
 def test_halo_tiles_reject_what_they_cannot_run():
