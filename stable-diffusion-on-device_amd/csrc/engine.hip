@@ -263,6 +263,8 @@ void Graph::set_param(const std::string& name, const void* data, int dtype, cons
         int32_t offset;
         std::memcpy(&scale, data, 4);
         std::memcpy(&offset, static_cast<const char*>(data) + 4, 4);
+        // the kernels fold the zero point into the fragment expansion: q + offset must be an exact fp16 integer (gemm.hip: u8x8_to_f16)
+        SDOD_REQUIRE(offset >= -1024 && offset <= 0, "'" + name + "': uint8 encoding offset must be in [-1024, 0] (QNN: -zero_point of a uint8 tensor)");
         const uint8_t* q = static_cast<const uint8_t*>(data) + 8;
         const int64_t rows = p.shape[0], kd = got / rows;
         std::vector<uint8_t> staging((size_t)got);

@@ -248,3 +248,20 @@ def test_config5_unet_step_at_768px(rig21):
         g.execute(True, static_unchanged=True)
     ev1.record(); torch.cuda.synchronize()
     print('config 5 UNet step @96x96, fp16 image of the uint8 weights: %.2f ms per replay' % (ev0.elapsed_time(ev1) / 5))
+
+
+def test_uint8_encoding_with_a_positive_offset_is_rejected_at_load():
+    """the kernels fold the zero point into the code expansion (q + offset must be an exact fp16 integer): a graph that keeps
+    its weights uint8 refuses an encoding outside [-1024, 0] instead of computing something else (engine.hip: set_param)"""
+    from sdod.amd import engine as E, weights as Wt
+    cfg = E.sd21_config(24, 24)
+    cfg.weight_quant = 1
+    g = E.Temb(cfg, 1)
+    sd = Wt.quantize_state_dict(Wt.synthetic_state_dict(g.param_table(), seed=5))
+    g.load_state_dict(sd)                         # the QNN-style encoding loads
+    name = next(k for k, v in sd.items() if isinstance(v, Wt.QuantU8))
+    bad = dict(sd)
+    bad[name] = Wt.QuantU8(sd[name].q, sd[name].scale, 7)
+    g2 = E.Temb(cfg, 1)
+    with pytest.raises(Exception, match='offset must be in'):
+        g2.load_state_dict(bad)
