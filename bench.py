@@ -66,7 +66,7 @@ def kernel_symbol(label):
             if st == 0:
                 return f'gemm_kernel<{bm}, {bn}, {wm}, {wn}>', f'gemm_kernelILi{bm}ELi{bn}ELi{wm}ELi{wn}EE'
             if spec == 2:    # halo-patch 3x3 convolution
-                return f'conv_halo_kernel<{bm}, {bn}, {wm}, {wn}, {st}>', f'conv_halo_kernelILi{bm}ELi{bn}ELi{wm}ELi{wn}ELi{st}EE'
+                return f'conv_halo_kernel<{bm}, {bn}, {wm}, {wn}, {st}, false>', f'conv_halo_kernelILi{bm}ELi{bn}ELi{wm}ELi{wn}ELi{st}ELb0EE'
             return (f'gemm_glds_kernel<{bm}, {bn}, {wm}, {wn}, {st}, {"true" if spec else "false"}, false, {ksub}>',
                     f'gemm_glds_kernelILi{bm}ELi{bn}ELi{wm}ELi{wn}ELi{st}ELb{spec}ELb0ELi{ksub}EE')
     plain = {'gn_group': 'gn_group_kernel<', 'gn_group_red': 'gn_group_kernel<', 'gn_grid': 'gn_grid_kernel<', 'gn_small': 'gn_small_kernel<', 'gn_stats_apply': 'gn_stats_kernel<', 'splitk_reduce': 'splitk_reduce_kernel',
