@@ -177,7 +177,7 @@ SDOD_API int sdod_group_norm_reduce_nhwc(const sdod_gn_reduce* red, const void* 
  * (+ bias_in[n]); W[n][k] <- fp16(W[n][k]*gamma[k]); s_out[n] = sum_k W'[n][k].  Used once per weight at graph build. */
 SDOD_API int sdod_ln_fold_f16(void* w, int n, int k, int ldw, const float* gamma, const float* beta, const float* bias_in,
                               float* s_out, float* t_out, void* stream);
-/* LayerNorm over the last dim of fp16 [M][C] rows, fp32 weight/bias. */
+/* LayerNorm over the last dim of fp16 [M][C] rows, fp32 weight/bias (either may be NULL); C % 8 == 0, C <= 3072. */
 SDOD_API int sdod_layer_norm_f16(const void* x, void* y, const float* weight, const float* bias, int m, int c,
                                  float eps, void* stream);
 

@@ -195,3 +195,17 @@ def test_group_norm_path_selection_without_a_gpu():
     assert lib.sdod_group_norm_path(1, 100, 64, 0, 32, 1) in (2, 3)     # fp32: LDS / two-pass kernels
     assert lib.sdod_group_norm_path(2, 64, 30, 0, 32, 0) == -1          # channels not divisible by groups
     assert lib.sdod_group_norm_workspace_bytes(2, 32) >= (2 * 1024 * 32 * 2 + 2 * 32 * 3 + 32 * 26) * 4
+
+
+def test_argument_checks_answer_before_any_launch():
+    """shape constraints of the kernel entry points are host-side checks: they answer (status + message) without a device"""
+    import ctypes
+    from sdod.amd import _lib
+    lib = _lib.hip()
+    buf = (ctypes.c_char * 64)()
+    P = ctypes.c_void_p
+    for c in (12, 4096):   # not a multiple of 8; wider than the 64-lanes-per-row kernel holds (6 x 16-byte chunks per lane)
+        assert lib.sdod_layer_norm_f16(ctypes.cast(buf, P), ctypes.cast(buf, P), None, None, 4, c, 1e-5, None) != 0
+        assert b'LayerNorm needs' in lib.sdod_hip_last_error()
+    assert lib.sdod_layer_norm_f16(None, None, None, None, 4, 64, 1e-5, None) != 0
+    assert b'null pointer' in lib.sdod_hip_last_error()
