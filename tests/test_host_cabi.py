@@ -209,3 +209,34 @@ def test_argument_checks_answer_before_any_launch():
         assert b'LayerNorm needs' in lib.sdod_hip_last_error()
     assert lib.sdod_layer_norm_f16(None, None, None, None, 4, 64, 1e-5, None) != 0
     assert b'null pointer' in lib.sdod_hip_last_error()
+
+
+def test_shipped_tile_table_is_well_formed():
+    """tune/gfx950.tune (the table every process builds its launch lists from): 12 key fields + pick per line, no duplicate
+    keys, tile ids the library knows, split factors in range; halo-patch picks only on 3x3 stride-1 convolutions whose
+    geometry the tile holds (sdod_gemm_plan keeps the chunk-granular plan) -- a stale or hand-edited table fails here, not on
+    the GPU box"""
+    import ctypes
+    import os
+    from sdod.amd import _lib
+    lib = _lib.hip()
+    path = os.path.join(os.path.dirname(_lib.LIB_DIR), 'tune', 'gfx950.tune')
+    assert os.path.exists(path), path
+    ntiles = lib.sdod_gemm_num_tiles()
+    seen = set()
+    info = (ctypes.c_int * 7)()
+    n_halo = 0
+    for ln, line in enumerate(open(path), 1):
+        v = line.split()
+        assert len(v) == 13, (ln, line)
+        v = [int(x) for x in v]
+        key = tuple(v[:12])
+        assert key not in seen, f'duplicate key on line {ln}'
+        seen.add(key)
+        tile, split = v[12] % 1000, v[12] // 1000
+        assert 1 <= tile <= ntiles and 1 <= split <= 64, (ln, v[12])
+        assert lib.sdod_gemm_tile_info(tile, info) == 0
+        if info[5] == 2:   # conv_halo_kernel: the key must be a 3x3 stride-1 convolution (a_mode 1, stride 1, ksize 3)
+            assert v[0] == 1 and v[6] == 1 and v[8] == 3, (ln, line)
+            n_halo += 1
+    assert len(seen) >= 600 and n_halo >= 100, (len(seen), n_halo)
