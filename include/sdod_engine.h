@@ -95,6 +95,10 @@ SDOD_API int sdod_graph_io(void* graph, int is_output, int index, void** device_
  * over a sampler run) have not changed since the previous execute, so the launches depending only on them are skipped */
 enum sdod_exec_flags { SDOD_EXEC_HIP_GRAPH = 1, SDOD_EXEC_STATIC_UNCHANGED = 2 };
 SDOD_API int sdod_graph_execute(void* graph, void* stream, int flags);
+/* Device-side failures a launch cannot report itself: LIBSDOD_RUNTIME_ERROR once a one-launch GroupNorm of any graph on this
+ * device has timed out at its grid barrier (sdod_group_norm_status, include/sdod_hip.h) -- call it behind a host
+ * synchronisation of the stream the graph ran on; sdod_graph_execute makes the same check on entry. */
+SDOD_API int sdod_graph_check(void* graph);
 /* launch list introspection + per-launch timing (HIP events on `stream`, eager, averaged over iters runs after one
  * warm-up): label = kernel family/variant ("gemm_t2", "gemm_t3_splitk", "attn_d40", "group_norm", ...), flops/bytes =
  * algorithmic work of that launch.  bench.py derives its roofline block from these. */

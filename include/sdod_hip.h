@@ -106,6 +106,10 @@ typedef struct sdod_gemm_desc {
      * tile, the slice that arrives last at the tile's counter reduces (in slice order: bit-identical to the reduce kernel)
      * and runs the fused epilogue.  NULL: partial slabs + splitk_reduce_kernel as before. */
     void* fix_counters;
+    /* XCD-aware tile order: 0 = chosen per shape (the number of n-tile panels in {1, 2, 4, 8} that minimises the bytes the
+     * eight L2s fetch between them, panels * A + (8 / panels) * W); 1 / 2 / 4 / 8 force it (1 = m-major: every XCD reads all
+     * of W; 8 = n-major: every XCD reads all of A).  Speed only. */
+    int xcd_panels;
 } sdod_gemm_desc;
 
 SDOD_API int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream);
@@ -117,6 +121,15 @@ SDOD_API size_t sdod_gemm_fixup_counters(void);
 SDOD_API size_t sdod_gemm_workspace_bytes(const sdod_gemm_desc* d);
 /* which tile configuration (1: 128x128, 2: 128x64, 3: 64x64, 4: 256x16, 5: 64x128) and split-K factor the call would use */
 SDOD_API int sdod_gemm_plan(const sdod_gemm_desc* d, int* tile, int* splits);
+/* 1 when halo-patch convolution tile `tile` takes the descriptor (3x3, stride 1, tile rows divide the image, patch fits LDS);
+ * 0 otherwise -- sdod_gemm_f16 refuses such a forced tile with LIBSDOD_INVALID_ARGUMENT.  Host-only. */
+SDOD_API int sdod_gemm_halo_ok(const sdod_gemm_desc* d, int tile);
+/* 1 when A-panel tile `tile` (gemm_apanel_kernel: a row panel x the whole K resident in LDS, n-tiles streamed past it) takes
+ * the descriptor: rows mode, fp16 weights, K >= 192, panel + ring within 160 KiB of LDS, no split-K / row_bias / bias2 /
+ * bias_on_m / tail segment.  Host-only. */
+SDOD_API int sdod_gemm_panel_ok(const sdod_gemm_desc* d, int tile);
+/* n-tile panels (1, 2, 4 or 8) of the XCD-aware tile order the call would use (see sdod_gemm_desc::xcd_panels).  Host-only. */
+SDOD_API int sdod_gemm_xcd_panels(const sdod_gemm_desc* d);
 /* number of tile configurations (valid `tile` values are 1..this); a tune table naming anything else is stale */
 SDOD_API int sdod_gemm_num_tiles(void);
 /* rows x columns of tile configuration `tile`; lds_dma = 1 for the LDS-DMA kernel family (tiles >= 6) */
@@ -133,10 +146,22 @@ SDOD_API int sdod_gemm_time_cold(const sdod_gemm_desc* d, void* stream, int iter
 
 /* GroupNorm over NHWC [N][HW][C] (optionally the channel concat of x (c0) and x2 (c1)), G groups,
  * y = (x-mean)*rstd*w+b, optional SiLU.  dtype applies to x and y; weight/bias fp32 or NULL.
- * workspace: >= sdod_group_norm_workspace_bytes(N, G) bytes of fp32 scratch, ZEROED ONCE by its owner before the first call
- * and never shared by two calls that may run concurrently (different streams: one workspace each): the one-launch kernel for
- * big maps (>= 5 MB) keeps the words of its grid barrier at the end of it and leaves them re-armed. */
+ * workspace: >= sdod_group_norm_workspace_bytes(N, G) bytes of fp32 scratch, 128-byte aligned, ZEROED ONCE by its owner before
+ * the first call and never shared by two calls that may run concurrently (different streams: one workspace each): the
+ * one-launch kernel for big maps (>= 5 MB) keeps the words of its grid barrier in the FIRST 4 KiB of it (a fixed offset, so
+ * that one workspace may serve calls of different (N, G): no layout's partial sums reach them) and leaves them re-armed.
+ * A grid barrier that cannot meet (barrier words clobbered; two such launches sharing one workspace or starving each other of
+ * CUs) gives up after ~1 s instead of hanging the device, and its output is INVALID.  It is never silent: the kernel sets a
+ * sticky per-device error word, after which sdod_group_norm_status() -- read it behind a host synchronisation -- and every
+ * later sdod_group_norm_nhwc / sdod_graph_execute on that device return LIBSDOD_RUNTIME_ERROR until the owner has re-zeroed
+ * the workspace and called sdod_group_norm_clear_error(). */
 SDOD_API size_t sdod_group_norm_workspace_bytes(int n, int groups);
+/* byte offsets of the workspace's parts for (n, groups): barrier lines, partial sums, statistics, pilot shifts, end */
+SDOD_API int sdod_group_norm_layout(int n, int groups, size_t* sync_off, size_t* partial_off, size_t* stats_off, size_t* shift_off,
+                                    size_t* end_off);
+/* 0, or LIBSDOD_RUNTIME_ERROR once a one-launch GroupNorm on the current device has timed out at its grid barrier (sticky) */
+SDOD_API int sdod_group_norm_status(void);
+SDOD_API int sdod_group_norm_clear_error(void);
 /* 1 = the single-launch kernel (whole image x channel set in LDS) handles this shape, 2 = statistics + apply launches */
 SDOD_API int sdod_group_norm_launches(int hw, int c, int groups, int dtype);
 /* which kernel the call below launches for this shape: 0 = one-launch grid-barrier kernel (maps >= 5 MB), 1 = one launch, a

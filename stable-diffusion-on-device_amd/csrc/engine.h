@@ -73,6 +73,7 @@ public:
     // skip_static: the inputs marked "static across a sampler run" (UNet: the text context) are unchanged since the
     // previous execute(), so the launches that depend only on them (all cross-attention K/V projections) are skipped
     void execute(hipStream_t st, bool use_hip_graph, bool skip_static = false);
+    void check_health() const; // throws RUNTIME_ERROR once a GroupNorm grid barrier has timed out on this device (sticky)
     IoSlot io(bool output, int index) const;
     void stats(size_t* wbytes, size_t* abytes, int* launches, double* flops) const;
 

@@ -971,8 +971,19 @@ void Graph::run_ops(hipStream_t st) {
     }
 }
 
+void Graph::check_health() const {
+    // the one-launch GroupNorm's grid barrier gives up after ~1 s rather than hang the device; what it then wrote is garbage
+    // and it says so through a sticky host-visible word (norms.hip).  Read here: at the next execute and wherever a caller
+    // has just synchronised (sdod_graph_check, Context::generate behind the image copy).
+    if (sdod_group_norm_status() != 0)
+        throw Error(RUNTIME_ERROR, "a GroupNorm grid barrier timed out on this device (workspace clobbered, or graphs sharing the device "
+                                   "starved each other of CUs): results since then are invalid; sdod_group_norm_clear_error() after "
+                                   "rebuilding the graph re-arms");
+}
+
 void Graph::execute(hipStream_t st, bool use_hip_graph, bool skip_static) {
     SDOD_REQUIRE(finalized_, "graph not finalized");
+    check_health();
     if (!skip_static || eager_runs_ == 0)
         for (auto& op : static_ops_) op.fn(st);
     if (!use_hip_graph || eager_runs_ == 0) {
@@ -1008,9 +1019,14 @@ void Graph::profile(hipStream_t st, int iters, float* ms, int n) {
     // GroupNorm) are stamped at their own begin / end by the command processor, i.e. the per-dispatch duration a profiler
     // reports -- no queue latency inside the figure
     constexpr int kMaxLaunches = 4;
-    std::vector<hipEvent_t> evs(ops_.size() * kMaxLaunches), eve(ops_.size() * kMaxLaunches);
-    for (auto& e : evs) SDOD_HIP_CHECK(hipEventCreate(&e));
-    for (auto& e : eve) SDOD_HIP_CHECK(hipEventCreate(&e));
+    struct Events { // destroyed on every exit path, an op that throws included
+        std::vector<hipEvent_t> v;
+        explicit Events(size_t n) : v(n, nullptr) {}
+        ~Events() { for (auto e : v) if (e) (void)hipEventDestroy(e); }
+        hipEvent_t& operator[](size_t i) { return v[i]; }
+    } evs(ops_.size() * kMaxLaunches), eve(ops_.size() * kMaxLaunches);
+    for (auto& e : evs.v) SDOD_HIP_CHECK(hipEventCreate(&e));
+    for (auto& e : eve.v) SDOD_HIP_CHECK(hipEventCreate(&e));
     std::vector<int> used(ops_.size(), 0);
     std::vector<std::vector<float>> samples(ops_.size());
     for (int it = 0; it < iters + 1; ++it) { // first pass is a warm-up
@@ -1045,8 +1061,6 @@ void Graph::profile(hipStream_t st, int iters, float* ms, int n) {
         const size_t k = samples[i].size();
         ms[i] = k == 0 ? 0.f : (k & 1) ? samples[i][k / 2] : 0.5f * (samples[i][k / 2 - 1] + samples[i][k / 2]);
     }
-    for (auto& e : evs) (void)hipEventDestroy(e);
-    for (auto& e : eve) (void)hipEventDestroy(e);
     ++eager_runs_;
 }
 
@@ -1163,6 +1177,14 @@ extern "C" int sdod_graph_execute(void* graph, void* stream, int use_hip_graph) 
     SDOD_TRY
     SDOD_REQUIRE(graph != nullptr, "null graph");
     static_cast<Graph*>(graph)->execute((hipStream_t)stream, (use_hip_graph & 1) != 0, (use_hip_graph & 2) != 0);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_graph_check(void* graph) {
+    SDOD_TRY
+    SDOD_REQUIRE(graph != nullptr, "null graph");
+    static_cast<Graph*>(graph)->check_health();
     return 0;
     SDOD_CATCH
 }

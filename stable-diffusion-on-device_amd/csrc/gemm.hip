@@ -81,6 +81,14 @@ struct GemmP {
     int h_colv_off;          // byte offset of the per-column epilogue vectors in LDS
     int h_main_splits;       // splits that walk the 3x3 taps (split h_main_splits, when k_tail != 0, walks the 1x1 tail)
     unsigned mg_tw, sh_tw, mg_th, sh_th, mg_pw, sh_pw, mg_pp, sh_pp;
+    // XCD-aware tile order (tile_of): the n-tiles are cut into xg panels, the first xg_r of them one tile wider (xg_w + 1);
+    // logical ids walk panel after panel, m-major inside a panel.  xg = 1 is the plain m-major order.
+    // A-panel kernel (gemm_apanel_kernel): workgroup = (row panel, group of ap_tpg consecutive n-tiles); ap_groups groups per panel
+    int ap_groups, ap_tpg, ap_panels, ap_nmajor;
+    int xg_w, xg_big;        // narrow panel width; ids below xg_big belong to the wide panels
+    int xg_s1, xg_s0;        // tiles per wide / narrow panel (tiles_m * width)
+    int xg_nbig;             // n-tiles covered by the wide panels
+    unsigned mg_s1, sh_s1, mg_s0, sh_s0, mg_w1, sh_w1, mg_w0, sh_w0;
 };
 
 constexpr int BK = 64;
@@ -95,6 +103,26 @@ inline void make_magic(unsigned d, unsigned* magic, unsigned* shift) {
     while ((1ull << s) < d) ++s;
     *shift = s;
     *magic = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+}
+
+// Logical tile id -> (tile_m, tile_n).  Workgroups b and b + 8 share an XCD (round-robin dispatch; speed only) and xcd_remap
+// hands each XCD a contiguous run of logical ids, so the ORDER of the ids decides which operand bytes each of the eight L2s
+// has to fetch: m-major ids give every XCD a band of m-tiles and ALL of W (fabric traffic A + 8 W), n-major ids all of A and
+// an eighth of W (8 A + W), and xg panels of n-tiles (8 / xg bands of m-tiles inside each) anything in between:
+// xg A + (8 / xg) W.  The host picks xg per shape (xcd_panels()).
+SDOD_DEVICE void tile_of(const GemmP& p, int lid, int& tile_m, int& tile_n) {
+    if (lid < p.xg_big) {
+        const int j = fast_div(lid, p.mg_s1, p.sh_s1);
+        const int o = lid - j * p.xg_s1;
+        tile_m = fast_div(o, p.mg_w1, p.sh_w1);
+        tile_n = j * (p.xg_w + 1) + (o - tile_m * (p.xg_w + 1));
+    } else {
+        const int l2 = lid - p.xg_big;
+        const int j = fast_div(l2, p.mg_s0, p.sh_s0);
+        const int o = l2 - j * p.xg_s0;
+        tile_m = fast_div(o, p.mg_w0, p.sh_w0);
+        tile_n = p.xg_nbig + j * p.xg_w + (o - tile_m * p.xg_w);
+    }
 }
 
 SDOD_DEVICE int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ (row & 7)) << 3); }
@@ -121,8 +149,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     // XCD-aware tile assignment: consecutive logical ids (same XCD) walk the n-tiles of one m-tile
     const int nwg = p.tiles_m * p.tiles_n;
     const int lid = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = lid / p.tiles_n;
-    const int tile_n = lid - tile_m * p.tiles_n;
+    int tile_m, tile_n;
+    tile_of(p, lid, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int split = blockIdx.z;
 
@@ -515,8 +543,8 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int lid = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = fast_div(lid, p.mg_tn, p.sh_tn);
-    const int tile_n = lid - tile_m * p.tiles_n;
+    int tile_m, tile_n;
+    tile_of(p, lid, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int split = blockIdx.z;
 
@@ -1220,6 +1248,294 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// A-PANEL kernel: the short-K, wide-N Linear layers of the transformer blocks (to_q|to_k|to_v with N = 3C, the GEGLU
+// projection with N = 8C; K = C = 320 / 640 / 1280, LayerNorm folded in).  In the ring kernel above these are the launches
+// furthest from the matrix pipe: a 128x128 tile has 5-20 slabs of K, so a workgroup lives for ~5 slabs of main loop between
+// a prologue that waits for its first bytes and an epilogue (1 + 1.5 + 2 us around 2.5 us of loop at K = 320), and every slab
+// re-streams 16 KB of A next to 16 KB of W at the ~80 GB/s a CU's LDS-DMA path sustains -- the matrix pipe needs a 32 KB slab
+// every 0.24 us (133 GB/s).  Here
+//   * a workgroup owns a row PANEL of BM rows x the whole K (80 KB: 128 x 320, 64 x 640 or 32 x 1280 halves), fetched into LDS
+//     ONCE, and walks several consecutive n-tiles against it: per slab only the W half (BN x 128 bytes) crosses L2 -> LDS,
+//     i.e. half the bytes per MFMA, and the LayerNorm row statistics are computed once per panel instead of once per tile;
+//   * the W slabs of ALL its tiles are one continuous stream through a ring (loader waves, as above): while the consumers
+//     run the epilogue of tile j the first slabs of tile j + 1 are already landing, and no tile after the first waits for
+//     first bytes;
+//   * the epilogue goes from the accumulators straight to global memory (8-byte row segments per lane; GEGLU halves them
+//     again): no LDS staging tile, hence no workgroup barrier besides the one per slab, and the loaders never take part.
+// One barrier per slab, counted vmcnt waits (conservative by the few epilogue-vector DMAs at a tile boundary), XOR-swizzled
+// slab images and fragment reads exactly as in gemm_glds_kernel.  Rows mode, fp16 weights, no split-K.
+template <int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(512) void gemm_apanel_kernel(const GemmP p, const f16* __restrict__ zeros) {
+    constexpr int NL = 4;                                   // loader waves (4..7); consumers are waves 0..3
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_LD = BM / (8 * NL), B_LD = BN / (8 * NL);
+    constexpr int AHEAD = STAGES - 1;
+    constexpr int ASLAB = BM * 64, WSLAB = BN * 64;         // halves per slab of the panel / of the ring
+    static_assert(WM * WN == 4 && BM % 32 == 0 && BN % 64 == 0 && TM >= 1 && TN >= 2 && TN % 2 == 0, "tile shape");
+    static_assert(B_LD * AHEAD + 2 < 64, "vmcnt is a 6-bit counter");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int KT = p.K / BK;
+    f16* sAp = reinterpret_cast<f16*>(smem_raw);            // [KT][BM][64]
+    f16* sW = sAp + (size_t)KT * ASLAB;                     // [STAGES][BN][64]
+    float* colv = reinterpret_cast<float*>(sW + (size_t)STAGES * WSLAB); // [2 tiles][bias | ln_s][BN]
+    float* ln_stats = colv + 4 * BN;                        // [BM][2] mean, rstd
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // workgroup -> (row panel, n-tile group).  Consecutive logical ids share an XCD (xcd_remap): the groups of one panel when
+    // the activations are the bigger operand (each L2 fetches its panels once, and all of W), the panels of one group when W is.
+    const int lid = xcd_remap(blockIdx.x, (int)gridDim.x);
+    int pm, ng;
+    if (p.ap_nmajor) {
+        ng = lid / p.ap_panels;
+        pm = lid - ng * p.ap_panels;
+    } else {
+        pm = lid / p.ap_groups;
+        ng = lid - pm * p.ap_groups;
+    }
+    const int t_begin = ng * p.ap_tpg;
+    const int T = min(p.tiles_n, t_begin + p.ap_tpg) - t_begin; // n-tiles of this workgroup
+    if (T <= 0) return;
+    const int m0 = pm * BM;
+    const int total = T * KT;                                    // W slabs this workgroup streams
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ lrow;
+
+    if (wave >= 4) {
+        // ---------------- LOADER program ----------------
+        const int lw = wave - 4;
+        unsigned a_off[A_LD], b_off[B_LD];
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int m = min(m0 + (i * NL + lw) * 8 + lrow, p.M - 1);
+            a_off[i] = ((unsigned)m * (unsigned)p.lda + (unsigned)lchunk * 8u) * 2u;
+        }
+        // the whole panel: KT x A_LD DMA instructions per wave, oldest things in flight
+        for (int kt = 0; kt < KT; ++kt) {
+            const f16* ab = p.a0 + kt * BK;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) lds_dma16_saddr(ab, a_off[i], sAp + (size_t)kt * ASLAB + (i * NL + lw) * 8 * 64);
+        }
+        int nj = 0, nit = 0, nslot = 0; // next slab to issue: tile, K slab, ring slot
+        auto issue_next = [&]() {
+            const int n0 = (t_begin + nj) * BN;
+            if (nit == 0) {
+                // a new tile: its per-column epilogue vectors (bias | LayerNorm-fold s) -> colv[nj & 1], older than its first slab;
+                // and the per-lane weight row offsets (rows past N clamp to the last one: they feed columns nobody stores)
+                const int vec = lw >> 1, q = lw & 1;
+                if (q * 64 < BN) {
+                    const int n = n0 + q * 64 + lane;
+                    const float* base = vec == 0 ? p.bias : (p.ln ? p.ln_s : nullptr);
+                    const float* g = (base != nullptr && n < p.N) ? base + n : reinterpret_cast<const float*>(zeros) + lane;
+                    __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(colv + ((nj & 1) * 2 + vec) * BN + q * 64), 4, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < B_LD; ++i) {
+                    const int n = min(n0 + (i * NL + lw) * 8 + lrow, p.N - 1);
+                    b_off[i] = ((unsigned)n * (unsigned)p.ldw + (unsigned)lchunk * 8u) * 2u;
+                }
+            }
+            const f16* wb = p.w + nit * BK;
+            f16* dst = sW + (size_t)nslot * WSLAB;
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) lds_dma16_saddr(wb, b_off[i], dst + (i * NL + lw) * 8 * 64);
+            if (++nit == KT) { nit = 0; ++nj; }
+            nslot = nslot + 1 == STAGES ? 0 : nslot + 1;
+        };
+#pragma unroll
+        for (int s = 0; s < AHEAD; ++s)
+            if (s < total) issue_next();
+        for (int g = 0; g < total; ++g) {
+            // slab g (and everything older: the panel, the tile's vectors) of THIS wave has landed once only younger slabs are
+            // outstanding; an epilogue-vector DMA among the younger ones makes the wait one instruction stricter, never looser
+            wait_younger<B_LD, STAGES - 2>(max(0, total - g - 1));
+            __builtin_amdgcn_s_barrier(); // ... and everybody's; the consumers have left slab g - 1
+            if (g == 0 && p.ln) {
+                // LayerNorm fold: row statistics of the panel, once: every lane re-reads the 16 bytes it DMA-ed per slab
+                float rs1[A_LD], rs2[A_LD];
+#pragma unroll
+                for (int i = 0; i < A_LD; ++i) rs1[i] = rs2[i] = 0.f;
+                for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                    for (int i = 0; i < A_LD; ++i) {
+                        const f16x8 v = *reinterpret_cast<const f16x8*>(sAp + (size_t)kt * ASLAB + (i * NL + lw) * 8 * 64 + lane * 8);
+                        const f16x2 one2 = {(f16)1.0f, (f16)1.0f};
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const f16x2 pr = {v[e], v[e + 1]};
+                            rs1[i] = __builtin_amdgcn_fdot2(pr, one2, rs1[i], false);
+                            rs2[i] = __builtin_amdgcn_fdot2(pr, pr, rs2[i], false);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < A_LD; ++i) {
+                    float a1 = rs1[i], a2 = rs2[i];
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) {
+                        a1 += __shfl_xor(a1, o);
+                        a2 += __shfl_xor(a2, o);
+                    }
+                    if ((lane & 7) == 0) {
+                        const float mean = a1 / (float)p.K;
+                        float var = a2 / (float)p.K - mean * mean;
+                        var = var < 0.f ? 0.f : var;
+                        const int r = (i * NL + lw) * 8 + lrow;
+                        ln_stats[2 * r] = mean;
+                        ln_stats[2 * r + 1] = 1.0f / sqrtf(var + p.ln_eps);
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the statistics are in LDS before this wave meets the next barrier
+            }
+            if (g + AHEAD < total) issue_next();
+        }
+        wait_vmcnt<0>();
+        return;
+    }
+
+    // ---------------- CONSUMER program ----------------
+    const int cw = wave;
+    const int wm = cw / WN, wn = cw % WN;
+    const int frag_row = lane & 15, frag_chunk = lane >> 4;
+    const int e_m = lane & 15, e_n = (lane >> 4) * 4;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    f16x8 fa[2][TM], fb[2][TN];
+    const unsigned a_base = (unsigned)(uintptr_t)(lds_void_ptr)sAp, w_base = (unsigned)(uintptr_t)(lds_void_ptr)sW;
+    unsigned a_addr[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_addr[i] = a_base + (unsigned)lds_off(wm * WTM + i * 16 + frag_row, frag_chunk) * 2u;
+    const unsigned b_addr0 = w_base + (unsigned)lds_off(wn * WTN + frag_row, frag_chunk) * 2u;
+    auto lds16 = [](unsigned addr) { return *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>((uintptr_t)addr); };
+    f32x4 acc[TM][TN];
+    auto read_half = [&](auto b_c, auto ks_c, int it, int slot) {
+        constexpr int b = decltype(b_c)::value, ks = decltype(ks_c)::value;
+        const unsigned abase = (unsigned)it * (unsigned)(ASLAB * 2);
+        const unsigned sb = (b_addr0 + (unsigned)slot * (unsigned)(WSLAB * 2)) ^ (ks << 6);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[b][i] = lds16((a_addr[i] + abase) ^ (ks << 6));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[b][j] = lds16(sb + j * 16 * 128);
+    };
+    auto mfma_half = [&](auto b_c) {
+        constexpr int b = decltype(b_c)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = mfma16(fb[b][j], fa[b][i], acc[i][j]);
+    };
+    auto interleave_reads_with_mfmas = [] {
+        constexpr int NRD = TM + TN, NMF = TM * TN, PAIRS = NRD < NMF ? NRD : NMF;
+        __builtin_amdgcn_sched_group_barrier(0x002, TM + 3, 0);
+        static_for<PAIRS>([](auto) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        });
+        if constexpr (NMF > PAIRS) __builtin_amdgcn_sched_group_barrier(0x008, NMF - PAIRS, 0);
+        if constexpr (NRD > PAIRS) __builtin_amdgcn_sched_group_barrier(0x100, NRD - PAIRS, 0);
+    };
+    const float alpha = p.alpha;
+    const int n_out = p.geglu ? p.N / 2 : p.N;
+    int slot = 0;
+    for (int jt = 0; jt < T; ++jt) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_s_barrier(); // the tile's first slab is in LDS (the loaders waited for it); for jt = 0 so is the panel
+        __builtin_amdgcn_sched_barrier(0);
+        read_half(I0{}, I0{}, 0, slot);
+        for (int it = 0; it < KT; ++it) {
+            read_half(I1{}, I1{}, it, slot);
+            mfma_half(I0{});
+            interleave_reads_with_mfmas();
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 1 < KT) {
+                __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): my reads of this slab are done, its slot may be refilled
+                __builtin_amdgcn_s_barrier();
+                slot = slot + 1 == STAGES ? 0 : slot + 1;
+                __builtin_amdgcn_sched_barrier(0);
+                read_half(I0{}, I0{}, it + 1, slot);
+            }
+            mfma_half(I1{});
+            interleave_reads_with_mfmas();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+        // ---- epilogue of tile jt, accumulators -> global (the loaders are already streaming tile jt + 1)
+        const int n0 = (t_begin + jt) * BN;
+        const float* cvb = colv + (jt & 1) * 2 * BN; // bias
+        const float* cvs = cvb + BN;                 // LayerNorm-fold s
+        if (p.geglu) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int ml = wm * WTM + i * 16 + e_m, m = m0 + ml;
+                const float mean = p.ln ? ln_stats[2 * ml] : 0.f, rstd = p.ln ? ln_stats[2 * ml + 1] : 1.f;
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const int nl = wn * WTN + j * 16 + e_n; // column of the value block in W-row space
+                    const f32x4 ba = *reinterpret_cast<const f32x4*>(cvb + nl), bg = *reinterpret_cast<const f32x4*>(cvb + nl + 16);
+                    const f32x4 sa = *reinterpret_cast<const f32x4*>(cvs + nl), sg = *reinterpret_cast<const f32x4*>(cvs + nl + 16);
+                    f16x4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float va = acc[i][j][r] * alpha, vg = acc[i][j + 1][r] * alpha;
+                        if (p.ln) {
+                            va = rstd * (va - mean * sa[r]);
+                            vg = rstd * (vg - mean * sg[r]);
+                        }
+                        va += ba[r];
+                        vg += bg[r];
+                        h[r] = (f16)(va * gelu_erf_f(vg));
+                    }
+                    const int col = (n0 + wn * WTN + j * 16) / 2 + e_n;
+                    if (m < p.M && col < n_out) *reinterpret_cast<f16x4*>(p.out + (size_t)m * p.ldo + col) = h;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int ml = wm * WTM + i * 16 + e_m, m = m0 + ml;
+                const float mean = p.ln ? ln_stats[2 * ml] : 0.f, rstd = p.ln ? ln_stats[2 * ml + 1] : 1.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int nl = wn * WTN + j * 16 + e_n, n = n0 + nl;
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(cvb + nl);
+                    const f32x4 sv = *reinterpret_cast<const f32x4*>(cvs + nl);
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float f = acc[i][j][r] * alpha;
+                        if (p.ln) f = rstd * (f - mean * sv[r]);
+                        f += b1[r];
+                        v[r] = f;
+                    }
+                    if (p.act != ACT_NONE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+                    }
+                    if (m < p.M && n < p.N) {
+                        if (p.residual != nullptr) {
+                            const f16x4 rr = *reinterpret_cast<const f16x4*>(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = (float)(f16)v[r] + (float)rr[r];
+                        }
+                        f16x4 h;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h[r] = (f16)v[r];
+                        *reinterpret_cast<f16x4*>(p.out + (size_t)m * p.ldo + n) = h;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // patch DMA rounds (256 lanes x 16 bytes each) a halo tile of bm output rows can need: (rows + 2) x (width + 2) pixels of 128
 // bytes.  96- and 192-row tiles exist for images whose rows are multiples of 3 (SD v2.1-768: 96 / 48 / 24 / 12 pixels)
 constexpr int halo_nrmax(int bm) { return bm <= 64 ? 7 : bm == 96 ? 10 : bm <= 128 ? 9 : 13; }
@@ -1296,8 +1612,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int lid = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = fast_div(lid, p.mg_tn, p.sh_tn);
-    const int tile_n = lid - tile_m * p.tiles_n;
+    int tile_m, tile_n;
+    tile_of(p, lid, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int split = blockIdx.z;
     const bool tail_wg = !WQ && p.k_tail != 0 && split == p.h_main_splits;
@@ -2013,8 +2329,14 @@ const TileCfg kTiles[] = {{0, 0},     {128, 128}, {128, 64}, {64, 64},   {256, 1
                           // workgroups of a 64-row tile at three quarters of its bytes per slab)
                           {32, 64}, {32, 128}, {32, 160},
                           // 49..52: halo-patch tiles of 96 / 192 rows, for images whose rows are multiples of 3 (config 5: 96 / 48 / 24 / 12)
-                          {96, 160}, {96, 64}, {192, 80}, {192, 64}};
-constexpr int kNumTiles = 52;
+                          {96, 160}, {96, 64}, {192, 80}, {192, 64},
+                          // 53..55: A-panel kernel (gemm_apanel_kernel): row panel x whole K resident in LDS, n-tiles streamed past it --
+                          // K = 320 / 640 / 1280 at 128 / 64 / 32 rows (80 KB panels)
+                          {128, 128}, {64, 128}, {32, 128}};
+constexpr int kNumTiles = 55;
+constexpr int kFirstPanelTile = 53, kLastPanelTile = 55;
+constexpr bool is_panel_tile(int t) { return t >= kFirstPanelTile && t <= kLastPanelTile; }
+constexpr int kPanelStages = 4;
 constexpr int kFirstHaloTile = 37, kLastHaloTile = 45, kFirstHaloTile3 = 49, kLastHaloTile3 = 52;
 constexpr bool is_halo_tile(int t) { return (t >= kFirstHaloTile && t <= kLastHaloTile) || (t >= kFirstHaloTile3 && t <= kLastHaloTile3); }
 // {STAGES} of the halo tiles (WM x WN is 2x2 for the 160- and 64-wide square-ish ones, 4x1 for the tall ones: launch switch)
@@ -2070,6 +2392,33 @@ hipError_t launch_halo_q(const GemmP& p, dim3 grid, size_t smem, hipStream_t st)
 template <int BM, int BN, int WM, int WN, int STAGES>
 hipError_t launch_halo(const GemmP& p, dim3 grid, size_t smem, hipStream_t st) {
     return p.wq ? launch_halo_q<BM, BN, WM, WN, STAGES, true>(p, grid, smem, st) : launch_halo_q<BM, BN, WM, WN, STAGES, false>(p, grid, smem, st);
+}
+
+size_t panel_smem(int bm, int bn, int K) {
+    return (size_t)(K / BK) * bm * 128 + (size_t)kPanelStages * bn * 128 + (size_t)4 * bn * sizeof(float) + (size_t)bm * 2 * sizeof(float);
+}
+// Does A-panel tile `tile` take descriptor d?  (plain row-major fp16 operands, the epilogues of the transformer Linears)
+bool panel_ok(const sdod_gemm_desc* d, int tile) {
+    if (!is_panel_tile(tile)) return false;
+    if (d->a_mode != SDOD_A_ROWS || d->wq || d->k_tail || d->bias_on_m || d->row_bias || d->bias2 || d->split_k > 1) return false;
+    if (d->K % BK || d->K / BK < 3 || d->N % 8 || d->ldo % 4 || (d->geglu && d->N % 32)) return false;
+    if (d->residual && (d->geglu || d->ldr % 4)) return false;
+    if ((unsigned long long)d->M * d->lda * 2 >= (1ull << 32) || (unsigned long long)d->N * d->ldw * 2 >= (1ull << 32)) return false;
+    return panel_smem(kTiles[tile].bm, kTiles[tile].bn, d->K) <= 160 * 1024;
+}
+
+template <int BM, int BN, int WM, int WN>
+hipError_t launch_panel(const GemmP& p, dim3 grid, size_t smem, hipStream_t st) {
+    static std::atomic<unsigned long long> attr_devs{0};
+    if (sdod::first_use_on_device(attr_devs)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_apanel_kernel<BM, BN, WM, WN, kPanelStages>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    const f16* z = zero_line();
+    if (!z) return hipErrorOutOfMemory;
+    SDOD_LAUNCH((gemm_apanel_kernel<BM, BN, WM, WN, kPanelStages>), grid, dim3(512), smem, st, p, z);
+    return hipGetLastError();
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -2154,6 +2503,44 @@ bool halo_geometry(const sdod_gemm_desc* d, int tile, GemmP* p, size_t* smem_byt
     return true;
 }
 
+// Panels of n-tiles for tile_of(): the xg in {1, 2, 4, 8} that minimises the bytes the eight L2s fetch between them,
+// xg * A + (8 / xg) * W (A = the activation operand as it sits in memory -- for a convolution the image, not its im2col; W =
+// the weight matrix), with xg <= tiles_n and 8 / xg <= tiles_m where the grid allows (a panel narrower than one tile, or a
+// band shorter than one, would spread nothing).  SDOD_GEMM_XCD=<1|2|4|8> forces one value (developer A/B switch);
+// sdod_gemm_desc::xcd_panels > 0 overrides both (tune table).
+int xcd_panels(const sdod_gemm_desc* d, int tiles_m, int tiles_n) {
+    static const int forced = [] {
+        const char* e = std::getenv("SDOD_GEMM_XCD");
+        const int v = e ? std::atoi(e) : 0;
+        return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0;
+    }();
+    int want = d->xcd_panels > 0 ? d->xcd_panels : forced;
+    if (want != 1 && want != 2 && want != 4 && want != 8) want = 0;
+    if (want) return std::min(want, std::max(1, tiles_n));
+    const double elem_w = d->wq ? 1.0 : 2.0;
+    const double a_bytes = d->a_mode == SDOD_A_ROWS ? (double)d->M * d->K * 2.0
+                                                    : (double)d->n_img * d->h_in * d->w_in * (double)(d->c0 + d->c1) * 2.0 +
+                                                          (double)d->M * (double)(d->tc0 + d->tc1) * 2.0;
+    const double w_bytes = (double)d->N * d->K * elem_w;
+    int best = 1;
+    double best_cost = 1e300;
+    for (int xg = 1; xg <= 8; xg *= 2) {
+        if (xg > tiles_n) break;
+        const int gm = 8 / xg;
+        if (gm > tiles_m && xg != 8) continue; // fewer m-tiles than bands: take more panels instead
+        const double cost = xg * a_bytes + gm * w_bytes;
+        if (cost < best_cost * 0.999) { // ties keep the smaller xg
+            best_cost = cost;
+            best = xg;
+        }
+    }
+    // Leave the m-major order unless the saving is worth having (>= 20 % of the bytes): panels also cut every output ROW
+    // between XCDs, and at the 64x64 level -- where A is the bigger operand anyway -- two panels bought the convolutions nothing
+    // and cost the GroupNorm behind them 0.8 us per launch (profiles/r03_xcd_orders.txt)
+    if (best != 1 && tiles_m >= 8 && best_cost > 0.8 * (a_bytes + 8 * w_bytes)) best = 1;
+    return best;
+}
+
 Plan make_plan(const sdod_gemm_desc* d) {
     Plan pl;
     const int KT = d->K / BK;
@@ -2191,6 +2578,11 @@ Plan make_plan(const sdod_gemm_desc* d) {
         }
     }
     pl.main_splits = 0;
+    if (is_panel_tile(tile)) { // one workgroup walks the whole K of its tiles (a descriptor it cannot run is rejected at launch)
+        pl.splits = 1;
+        pl.kt_per_split = KT;
+        return pl;
+    }
     if (is_halo_tile(tile) && halo_geometry(d, tile, nullptr, nullptr)) { // (a descriptor it cannot run is rejected at launch)
         // whole 64-channel chunks (9 tap slabs) per split; the 1x1 tail, if any, is one more slice
         const int nmain = (d->c0 + d->c1) / BK;
@@ -2292,7 +2684,9 @@ extern "C" int sdod_gemm_tile_info(int tile, int out[7]) {
         {64, 160, 2, 2, 4, 2, 1}, {128, 80, 4, 1, 4, 2, 1}, {128, 160, 2, 2, 3, 2, 1}, {64, 80, 4, 1, 4, 2, 1}, {256, 32, 4, 1, 6, 2, 1},
         {128, 32, 4, 1, 6, 2, 1}, {256, 64, 4, 1, 4, 2, 1}, {128, 64, 2, 2, 4, 2, 1}, {64, 64, 2, 2, 4, 2, 1},
         {32, 64, 2, 2, 6, 1, 1}, {32, 128, 1, 4, 6, 1, 1}, {32, 160, 2, 2, 4, 1, 1},
-        {96, 160, 2, 2, 3, 2, 1}, {96, 64, 2, 2, 4, 2, 1}, {192, 80, 4, 1, 4, 2, 1}, {192, 64, 4, 1, 4, 2, 1}};
+        {96, 160, 2, 2, 3, 2, 1}, {96, 64, 2, 2, 4, 2, 1}, {192, 80, 4, 1, 4, 2, 1}, {192, 64, 4, 1, 4, 2, 1},
+        // SPEC column 3 = gemm_apanel_kernel<BM, BN, WM, WN, STAGES>
+        {128, 128, 2, 2, kPanelStages, 3, 1}, {64, 128, 2, 2, kPanelStages, 3, 1}, {32, 128, 1, 4, kPanelStages, 3, 1}};
     static_assert(sizeof(kInfo) / sizeof(kInfo[0]) == kNumTiles + 1, "one row per tile");
     if (tile < 1 || tile > kNumTiles || !out) return sdod::INVALID_ARGUMENT;
     for (int i = 0; i < 7; ++i) out[i] = kInfo[tile][i];
@@ -2305,6 +2699,23 @@ extern "C" int sdod_gemm_tile_shape(int tile, int* bm, int* bn, int* lds_dma) {
     if (bn) *bn = kTiles[tile].bn;
     if (lds_dma) *lds_dma = tile >= 6 ? 1 : 0;
     return 0;
+}
+
+extern "C" int sdod_gemm_panel_ok(const sdod_gemm_desc* d, int tile) {
+    if (!d || d->K <= 0 || tile < 1 || tile > kNumTiles) return 0;
+    return panel_ok(d, tile) ? 1 : 0;
+}
+
+extern "C" int sdod_gemm_halo_ok(const sdod_gemm_desc* d, int tile) {
+    if (!d || d->K <= 0 || d->K % BK || tile < 1 || tile > kNumTiles) return 0;
+    return halo_geometry(d, tile, nullptr, nullptr) ? 1 : 0;
+}
+
+extern "C" int sdod_gemm_xcd_panels(const sdod_gemm_desc* d) {
+    if (!d || d->K <= 0 || d->K % BK || d->M <= 0 || d->N <= 0) return 0;
+    const Plan pl = make_plan(d);
+    const TileCfg tc = kTiles[pl.tile];
+    return xcd_panels(d, (d->M + tc.bm - 1) / tc.bm, (d->N + tc.bn - 1) / tc.bn);
 }
 
 extern "C" int sdod_gemm_plan(const sdod_gemm_desc* d, int* tile, int* splits) {
@@ -2416,11 +2827,42 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     make_magic((unsigned)(p.h_out * p.w_out), &p.mg_hw, &p.sh_hw);
     make_magic((unsigned)p.w_out, &p.mg_w, &p.sh_w);
     make_magic((unsigned)p.tiles_n, &p.mg_tn, &p.sh_tn);
+    {
+        const int xg = xcd_panels(d, p.tiles_m, p.tiles_n);
+        const int w = p.tiles_n / xg, r = p.tiles_n % xg;
+        p.xg_w = w;
+        p.xg_s1 = p.tiles_m * (w + 1);
+        p.xg_s0 = p.tiles_m * w;
+        p.xg_big = r * p.xg_s1;
+        p.xg_nbig = r * (w + 1);
+        make_magic((unsigned)p.xg_s1, &p.mg_s1, &p.sh_s1);
+        make_magic((unsigned)p.xg_s0, &p.mg_s0, &p.sh_s0);
+        make_magic((unsigned)(w + 1), &p.mg_w1, &p.sh_w1);
+        make_magic((unsigned)w, &p.mg_w0, &p.sh_w0);
+    }
     make_magic((unsigned)(p.c0 + p.c1), &p.mg_cin, &p.sh_cin);
     dim3 grid(p.tiles_m * p.tiles_n, 1, pl.splits);
     hipStream_t st = (hipStream_t)stream;
     SDOD_REQUIRE(d->phase >= 0 && d->phase <= 2 && (d->phase == 0 || pl.splits > 1), "phase 1/2 only apply to a split-K plan");
     hipError_t e = hipSuccess;
+    if (is_panel_tile(pl.tile)) {
+        SDOD_REQUIRE(panel_ok(d, pl.tile), "this A-panel tile does not take the GEMM (plain rows x fp16 weights, K >= 192, the row panel must fit LDS)");
+        // grid: one workgroup per (row panel, group of consecutive n-tiles), about one per CU
+        p.ap_panels = p.tiles_m;
+        int groups = std::max(1, std::min(p.tiles_n, (256 + p.ap_panels / 2) / p.ap_panels));
+        p.ap_tpg = (p.tiles_n + groups - 1) / groups;
+        p.ap_groups = (p.tiles_n + p.ap_tpg - 1) / p.ap_tpg;
+        p.ap_nmajor = (double)d->N * d->K > (double)d->M * d->K ? 1 : 0; // W the bigger operand: an XCD keeps a group's W, not a panel's A
+        const size_t smem = panel_smem(tc.bm, tc.bn, d->K);
+        const dim3 pgrid(p.ap_panels * p.ap_groups);
+        switch (pl.tile) {
+        case 53: e = launch_panel<128, 128, 2, 2>(p, pgrid, smem, st); break;
+        case 54: e = launch_panel<64, 128, 2, 2>(p, pgrid, smem, st); break;
+        default: e = launch_panel<32, 128, 1, 4>(p, pgrid, smem, st); break;
+        }
+        SDOD_HIP_CHECK(e);
+        return 0;
+    }
     const bool halo_tile = is_halo_tile(pl.tile); // (takes uint8 weights itself: launch_halo)
     if (d->phase != 2 && d->wq && !halo_tile)
     switch (pl.tile) { // the uint8-weight variants (make_plan maps every other tile onto one of these)

@@ -47,6 +47,8 @@ Context::~Context() {
     for (void* p : {(void*)temb_cache_, (void*)ctx_uncond_, (void*)e_dev_, (void*)y_prev_, (void*)x_dev_, (void*)img_u8_})
         if (p) (void)hipFree(p);
     unet_.reset(); text_.reset(); vae_.reset(); temb_.reset();
+    for (hipEvent_t e : phase_events_)
+        if (e) (void)hipEventDestroy(e);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -129,6 +131,14 @@ void Context::set_initial_latent(const float* x, size_t n) {
     injected_ = true;
 }
 
+namespace {
+std::string ms_str(double ms) {
+    char b[32];
+    std::snprintf(b, sizeof b, "%.2f", ms);
+    return b;
+}
+} // namespace
+
 void Context::generate(const std::string& prompt, float guidance, unsigned char* out) {
     SDOD_REQUIRE(unet_ && text_ && vae_ && temb_cache_ && steps_ > 0, "context is not initialised");
     SDOD_HIP_CHECK(hipSetDevice(device_));
@@ -142,11 +152,24 @@ void Context::generate(const std::string& prompt, float guidance, unsigned char*
     const IoSlot ux = unet_->io(false, 0), ut = unet_->io(false, 1), uc = unet_->io(false, 2), ue = unet_->io(true, 0);
     const size_t temb_row = ut.bytes / 2; // one row of projected time conditioning (two batch rows in the UNet slot)
 
-    Timer t;
+    // The reference brackets its four timers with host clocks because its host loop waits for the device after every graph
+    // (context.cpp:324-331, :343-381, :383-398, :402).  Here nothing waits before the image copy, so the phases are bracketed
+    // by EVENTS on the stream and read once after the final synchronisation: every one of the reference's INFO lines, no stall.
+    const bool timed = (unsigned)logger_.level() >= (unsigned)LogLevel::INFO;
+    if (timed && phase_events_.size() < (size_t)steps_ + 3) {
+        const size_t have = phase_events_.size();
+        phase_events_.resize((size_t)steps_ + 3, nullptr);
+        for (size_t i = have; i < phase_events_.size(); ++i) SDOD_HIP_CHECK(hipEventCreate(&phase_events_[i]));
+    }
+    auto mark = [&](size_t i) {
+        if (timed) SDOD_HIP_CHECK(hipEventRecord(phase_events_[i], stream_));
+    };
+
+    mark(0);
     // row 0 = conditional, row 1 = unconditional
     encode_prompt(prompt, static_cast<f16*>(uc.ptr));
     SDOD_HIP_CHECK(hipMemcpyAsync(static_cast<char*>(uc.ptr) + ctx_bytes, ctx_uncond_, ctx_bytes, hipMemcpyDeviceToDevice, stream_));
-    logger_.info("Conditioning took " + std::to_string((long)t.ms()) + "ms");
+    mark(1);
 
     if (!injected_)
         for (auto& f : x_host_) f = normal_(rng_); // context.cpp:333-334
@@ -154,7 +177,6 @@ void Context::generate(const std::string& prompt, float guidance, unsigned char*
     SDOD_HIP_CHECK(hipMemcpyAsync(x_dev_, x_host_.data(), lat * sizeof(float), hipMemcpyHostToDevice, stream_));
 
     for (unsigned step = 0; step < steps_; ++step) {
-        t = Timer();
         // both batch rows see the same latent and time embedding (context.cpp:348-352, :364-366): one staging launch
         const char* te = reinterpret_cast<const char*>(temb_cache_) + step * temb_row;
         rc_check(sdod_stage_unet_inputs(x_dev_, static_cast<float*>(ux.ptr), lat, 2, te, ut.ptr, temb_row / sizeof(f16), 2, stream_));
@@ -163,25 +185,32 @@ void Context::generate(const std::string& prompt, float guidance, unsigned char*
         rc_check(sdod_cfg_combine(ue.ptr, e_dev_, 1, C, HW, guidance, /*uncond_first=*/0, /*mode=*/0, stream_));
         const DpmSolver::StepCoef k = solver_->coef(step);
         rc_check(sdod_dpm_update(x_dev_, e_dev_, y_prev_, lat, k.order, k.sigma_s, k.alpha_s, k.sigma_ratio, k.c_prev, k.c_cur, stream_));
-        // the reference logs every iteration at INFO (context.cpp:381) because its host loop waits for the device anyway;
-        // here a per-step synchronisation would stall the launch queue, so only DEBUG (and above) pays for it
-        if ((unsigned)logger_.level() >= (unsigned)LogLevel::DEBUG) {
-            SDOD_HIP_CHECK(hipStreamSynchronize(stream_));
-            logger_.debug("Single iteration took " + std::to_string((long)t.ms()) + "ms");
-        }
+        mark(2 + step);
     }
 
-    t = Timer();
     const IoSlot vz = vae_->io(false, 0), vi = vae_->io(true, 0);
     SDOD_HIP_CHECK(hipMemcpyAsync(vz.ptr, x_dev_, lat * sizeof(float), hipMemcpyDeviceToDevice, stream_));
     vae_->execute(stream_, true);
     // context.cpp:392-395: uint8(clamp(255*f, 0, 255)) with f = (decoded + 1)/2
     rc_check(sdod_image_to_u8(vi.ptr, img_u8_, image_bytes(), 0.5f, 0.5f, 0, stream_));
     SDOD_HIP_CHECK(hipMemcpyAsync(out, img_u8_, image_bytes(), hipMemcpyDeviceToHost, stream_));
+    mark(2 + steps_);
     SDOD_HIP_CHECK(hipStreamSynchronize(stream_));
-    logger_.info("Decoding took " + std::to_string((long)t.ms()) + "ms");
+    unet_->check_health(); // a launch that could not report its own failure (GroupNorm grid barrier): no image is better than a wrong one
+
+    if (timed) {
+        auto between = [&](size_t a, size_t b) {
+            float ms = 0.f;
+            SDOD_HIP_CHECK(hipEventElapsedTime(&ms, phase_events_[a], phase_events_[b]));
+            return (double)ms;
+        };
+        logger_.info("Conditioning took " + ms_str(between(0, 1)) + "ms");                 // context.cpp:331
+        for (unsigned step = 0; step < steps_; ++step)                                      // context.cpp:381
+            logger_.info("Single iteration took " + ms_str(between(1 + step, 2 + step)) + "ms");
+        logger_.info("Decoding took " + ms_str(between(1 + steps_, 2 + steps_)) + "ms");   // context.cpp:398 (decode + uint8 + copy only)
+    }
     logger_.info("Image successfully generated!");
-    logger_.info("Image generation took " + std::to_string((long)total.ms()) + "ms");
+    logger_.info("Image generation took " + ms_str(total.ms()) + "ms");                    // context.cpp:402 (host clock, whole call)
 }
 
 } // namespace sdod

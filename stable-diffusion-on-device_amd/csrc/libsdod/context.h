@@ -65,6 +65,7 @@ private:
     std::vector<float> model_ts_;
 
     hipStream_t stream_ = nullptr;
+    std::vector<hipEvent_t> phase_events_; // generate()'s phase boundaries: start, conditioning, every iteration, decode
     f16* temb_cache_ = nullptr;   // [steps][4*model_ch]
     f16* ctx_uncond_ = nullptr;   // [77][ctx_dim]
     float* e_dev_ = nullptr;      // CFG result, fp32 NCHW

@@ -837,8 +837,9 @@ constexpr int GN_MAX_CHUNKS_GRID = 256;
 //   Grid barrier: a small counter tree + generation words in the caller's workspace (sdod_group_norm_workspace_bytes;
 //   zeroed once by its owner, re-armed by every launch).  Every workgroup must be resident: the grid is at most one
 //   workgroup per CU (512 threads, < 32 KB LDS: several fit per CU, so a few such kernels on different streams still
-//   co-reside).  The wait is bounded: a launch that cannot meet (counter clobbered) gives up after ~2^21 polls instead
-//   of hanging the device.
+//   co-reside).  The wait is bounded: a launch that cannot meet (counter clobbered, or two grids that
+//   starve each other of CUs) gives up after 2^20 polls (~1 s) instead of hanging the device, and says so: a sticky error word
+//   (gn_error_word(), sdod_group_norm_status) that turns the caller's next host-side check into LIBSDOD_RUNTIME_ERROR.
 struct GnGridP {
     const f16* x0;
     const f16* x1;
@@ -846,7 +847,9 @@ struct GnGridP {
     const float* w;
     const float* b;
     float* partial;   // [N][wpi][G][2]
-    unsigned* sync;   // 25 words, one per 128-byte line: [0] top counter, [1..16] shard counters, [17..24] generation replicas
+    unsigned* sync;   // 25 words, one per 128-byte line: [0] top counter, [1..16] shard counters, [17..24] generation replicas;
+                      // line 25 = the workspace's sticky timeout word
+    unsigned* err_host; // host-mapped sticky error word of this device (may be null): a timed-out barrier is reported, see below
     int N, HW, C0, C1, C, G, Cg;
     int cp, rp;       // 16-byte chunks per pixel row; pixel rows per pass of the 512 threads
     int wpi, ppw, nwg; // workgroups per image, pixels per workgroup, workgroups in the grid
@@ -955,9 +958,17 @@ __global__ __launch_bounds__(512) void gn_grid_kernel(const GnGridP p) {
         }
         if (!opened) {
             const unsigned* flag = p.sync + 32 * (17 + (blockIdx.x & 7));
-            for (int spin = 0; spin < (1 << 20); ++spin) { // bounded: a clobbered workspace ends in wrong numbers, not in a hung device
-                if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen0) break;
+            bool met = false;
+            for (int spin = 0; spin < (1 << 20); ++spin) { // bounded (~1 s): a clobbered workspace must not hang the device ...
+                if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen0) { met = true; break; }
                 __builtin_amdgcn_s_sleep(6);
+            }
+            if (!met) {
+                // ... and must not pass for a result either: the partials below are incomplete.  Sticky words, never cleared by a
+                // kernel: one in the workspace (its owner re-zeroes a workspace that reports this) and the device's host-mapped
+                // word, which sdod_group_norm_nhwc / sdod_group_norm_status / the graph engine read after the next host sync.
+                __hip_atomic_store(p.sync + 32 * 25, 0x0bad0bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (p.err_host) __hip_atomic_store(p.err_host, 0x0bad0bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -1068,6 +1079,26 @@ static int gn_grid_plan(int n, int hw, int c0, int c1, int groups, GnGridP* out)
     return k <= 4 ? 4 : k <= 8 ? 8 : 16;
 }
 
+// Host-mapped sticky error word, one per device (the pointer is only valid on the device that allocated it).  Allocated on a
+// host-side entry point that always precedes the first launch (sdod_group_norm_workspace_bytes), never inside a stream capture.
+static unsigned* gn_error_word(bool allocate) {
+    static std::atomic<unsigned*> words[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    unsigned* cur = words[dev].load(std::memory_order_acquire);
+    if (!cur && allocate) {
+        unsigned* fresh = nullptr;
+        if (hipHostMalloc((void**)&fresh, 128, hipHostMallocMapped) != hipSuccess || !fresh) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        *fresh = 0u;
+        if (words[dev].compare_exchange_strong(cur, fresh, std::memory_order_acq_rel)) cur = fresh;
+        else (void)hipHostFree(fresh);
+    }
+    return cur;
+}
+
 static bool gn_grid_try(const GnP& q, hipStream_t st) {
     GnGridP p{};
     const int kmax = gn_grid_plan(q.N, q.HW, q.C0, q.C1, q.G, &p);
@@ -1075,6 +1106,7 @@ static bool gn_grid_try(const GnP& q, hipStream_t st) {
     p.x0 = (const f16*)q.x0; p.x1 = (const f16*)q.x1; p.y = (f16*)q.y; p.w = q.w; p.b = q.b;
     p.partial = q.partial;
     p.sync = reinterpret_cast<unsigned*>(q.sync);
+    p.err_host = gn_error_word(false);
     p.N = q.N; p.HW = q.HW; p.C0 = q.C0; p.C1 = q.C1; p.C = q.C; p.G = q.G; p.Cg = q.Cg; p.eps = q.eps; p.silu = q.silu;
     const size_t smem = ((size_t)q.C * 2 + (size_t)q.G * 2) * sizeof(float);
     if (kmax == 4) SDOD_LAUNCH((gn_grid_kernel<4>), dim3(p.nwg), dim3(512), smem, st, p);
@@ -1338,9 +1370,39 @@ extern "C" int sdod_group_norm_reduce_nhwc(const sdod_gn_reduce* red, const void
     SDOD_CATCH
 }
 
+// Workspace layout (floats): [0, GN_SYNC_FLOATS) the grid barrier's 25 counter lines + the sticky timeout word (line 25), at a
+// FIXED offset in front of everything else, so that no (n, groups) layout of the partials of one call can reach the barrier
+// words another call's layout uses (one grow-only workspace serves every shape of a process); then partial
+// [n][GN_MAX_CHUNKS][groups][2], stats [n][groups][2], shift [n][groups].
+constexpr size_t GN_SYNC_FLOATS = 1024;
 extern "C" size_t sdod_group_norm_workspace_bytes(int n, int groups) {
     if (n <= 0 || groups <= 0) return 0;
-    return ((size_t)n * GN_MAX_CHUNKS * groups * 2 + (size_t)n * groups * 3 + 32 * 26) * sizeof(float); // + the grid-barrier lines
+    (void)gn_error_word(true);
+    return (GN_SYNC_FLOATS + (size_t)n * GN_MAX_CHUNKS * groups * 2 + (size_t)n * groups * 3) * sizeof(float);
+}
+
+extern "C" int sdod_group_norm_layout(int n, int groups, size_t* sync_off, size_t* partial_off, size_t* stats_off, size_t* shift_off,
+                                      size_t* end_off) {
+    if (n <= 0 || groups <= 0) return sdod::INVALID_ARGUMENT;
+    const size_t part = GN_SYNC_FLOATS * sizeof(float), st = part + (size_t)n * GN_MAX_CHUNKS * groups * 2 * sizeof(float);
+    const size_t sh = st + (size_t)n * groups * 2 * sizeof(float);
+    if (sync_off) *sync_off = 0;
+    if (partial_off) *partial_off = part;
+    if (stats_off) *stats_off = st;
+    if (shift_off) *shift_off = sh;
+    if (end_off) *end_off = sh + (size_t)n * groups * sizeof(float);
+    return 0;
+}
+
+extern "C" int sdod_group_norm_status(void) {
+    const unsigned* w = gn_error_word(false);
+    return (w && *reinterpret_cast<const volatile unsigned*>(w) != 0u) ? sdod::RUNTIME_ERROR : 0;
+}
+
+extern "C" int sdod_group_norm_clear_error(void) {
+    unsigned* w = gn_error_word(false);
+    if (w) *reinterpret_cast<volatile unsigned*>(w) = 0u;
+    return 0;
 }
 
 extern "C" int sdod_group_norm_nhwc(const void* x, const void* x2, void* y, const float* weight, const float* bias, int n,
@@ -1369,10 +1431,15 @@ extern "C" int sdod_group_norm_nhwc(const void* x, const void* x2, void* y, cons
     if (nchunks > hw) nchunks = hw;
     p.pix_per_chunk = (hw + nchunks - 1) / nchunks;
     p.nchunks = (hw + p.pix_per_chunk - 1) / p.pix_per_chunk;
-    p.partial = (float*)workspace;
+    SDOD_REQUIRE(((uintptr_t)workspace & 127) == 0, "workspace must be 128-byte aligned");
+    if (sdod_group_norm_status() != 0)
+        throw sdod::Error(sdod::RUNTIME_ERROR, std::string(__func__) +
+                          ": an earlier one-launch GroupNorm timed out at its grid barrier (workspace clobbered, or shared by concurrent "
+                          "launches): its output is invalid; re-zero the workspace and call sdod_group_norm_clear_error()");
+    p.sync = workspace; // 26 lines of 128 bytes at the fixed front of the workspace (sdod_group_norm_workspace_bytes)
+    p.partial = (float*)workspace + GN_SYNC_FLOATS;
     p.stats = p.partial + (size_t)n * GN_MAX_CHUNKS * groups * 2;
     p.shift = p.stats + (size_t)n * groups * 2;
-    p.sync = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(p.shift + (size_t)n * groups) + 127) & ~(uintptr_t)127); // 25 lines of 128 bytes
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SDOD_F16) gn_launch<f16>(p, st);
     else gn_launch<float>(p, st);

@@ -54,7 +54,7 @@ class GemmDesc(ctypes.Structure):
         ('act', c_int), ('alpha', c_float), ('bias_on_m', c_int), ('split_k', c_int), ('tile', c_int),
         ('geglu', c_int), ('k_tail', c_int), ('t0', c_void_p), ('t1', c_void_p), ('tc0', c_int), ('tc1', c_int),
         ('bias2', c_void_p), ('ln', c_int), ('ln_s', c_void_p), ('ln_eps', c_float), ('phase', c_int),
-        ('wq', c_int), ('w_scale', c_void_p), ('w_off', c_void_p), ('fix_counters', c_void_p),
+        ('wq', c_int), ('w_scale', c_void_p), ('w_off', c_void_p), ('fix_counters', c_void_p), ('xcd_panels', c_int),
     ]
 
 
@@ -66,6 +66,9 @@ def _declare(lib):
         'sdod_gemm_fixup_counters': (c_size_t, []),
         'sdod_gemm_workspace_bytes': (c_size_t, [ctypes.POINTER(GemmDesc)]),
         'sdod_gemm_plan': (c_int, [ctypes.POINTER(GemmDesc), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+        'sdod_gemm_halo_ok': (c_int, [ctypes.POINTER(GemmDesc), c_int]),
+        'sdod_gemm_panel_ok': (c_int, [ctypes.POINTER(GemmDesc), c_int]),
+        'sdod_gemm_xcd_panels': (c_int, [ctypes.POINTER(GemmDesc)]),
         'sdod_gemm_time': (c_int, [ctypes.POINTER(GemmDesc), P, c_int, ctypes.POINTER(c_float)]),
         'sdod_gemm_time_cold': (c_int, [ctypes.POINTER(GemmDesc), P, c_int, P, c_size_t, ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),
         'sdod_gemm_num_tiles': (c_int, []),
@@ -76,6 +79,9 @@ def _declare(lib):
         'sdod_group_norm_reduce_nhwc': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
         'sdod_group_norm_launches': (c_int, [c_int, c_int, c_int, c_int]),
         'sdod_group_norm_workspace_bytes': (c_size_t, [c_int, c_int]),
+        'sdod_group_norm_layout': (c_int, [c_int, c_int] + [ctypes.POINTER(c_size_t)] * 5),
+        'sdod_group_norm_status': (c_int, []),
+        'sdod_group_norm_clear_error': (c_int, []),
         'sdod_group_norm_path': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
         'sdod_group_norm_nhwc': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, P, P]),
         'sdod_layer_norm_f16': (c_int, [P, P, P, P, c_int, c_int, c_float, P]),
@@ -109,7 +115,7 @@ def _declare(lib):
 
 
 HIP_SYMBOLS = [
-    'sdod_gemm_f16', 'sdod_gemm_fixup', 'sdod_gemm_fixup_counters', 'sdod_gemm_workspace_bytes', 'sdod_gemm_plan', 'sdod_gemm_num_tiles', 'sdod_gemm_tile_shape', 'sdod_gemm_tile_info', 'sdod_gemm_time', 'sdod_gemm_time_cold', 'sdod_group_norm_workspace_bytes', 'sdod_l2_prefetch', 'sdod_group_norm_launches', 'sdod_group_norm_path', 'sdod_group_norm_nhwc', 'sdod_gemm_reduce_info', 'sdod_group_norm_reduce_ok', 'sdod_group_norm_reduce_nhwc',
+    'sdod_gemm_f16', 'sdod_gemm_fixup', 'sdod_gemm_fixup_counters', 'sdod_gemm_workspace_bytes', 'sdod_gemm_plan', 'sdod_gemm_halo_ok', 'sdod_gemm_panel_ok', 'sdod_gemm_xcd_panels', 'sdod_gemm_num_tiles', 'sdod_gemm_tile_shape', 'sdod_gemm_tile_info', 'sdod_gemm_time', 'sdod_gemm_time_cold', 'sdod_group_norm_workspace_bytes', 'sdod_group_norm_layout', 'sdod_group_norm_status', 'sdod_group_norm_clear_error', 'sdod_l2_prefetch', 'sdod_group_norm_launches', 'sdod_group_norm_path', 'sdod_group_norm_nhwc', 'sdod_gemm_reduce_info', 'sdod_group_norm_reduce_ok', 'sdod_group_norm_reduce_nhwc',
     'sdod_layer_norm_f16', 'sdod_ln_fold_f16', 'sdod_attention_f16', 'sdod_softmax_rows_f16', 'sdod_geglu_f16', 'sdod_act_f16',
     'sdod_add_f16', 'sdod_concat_channels_f16', 'sdod_im2col3x3_small_f16', 'sdod_nchw_f32_to_nhwc_f16',
     'sdod_nhwc_f16_to_nchw_f32', 'sdod_latent_prep_f16', 'sdod_embedding_f16', 'sdod_timestep_features_f16', 'sdod_cfg_combine', 'sdod_stage_unet_inputs', 'sdod_randn_f32',

@@ -21,7 +21,7 @@ class ModelConfig(ctypes.Structure):
 
 ENGINE_SYMBOLS = [
     'sdod_model_config_sd14', 'sdod_model_config_sd21', 'sdod_graph_create', 'sdod_graph_destroy', 'sdod_graph_num_params', 'sdod_graph_param_info',
-    'sdod_graph_set_param', 'sdod_graph_load_file', 'sdod_graph_finalize', 'sdod_graph_io', 'sdod_graph_execute',
+    'sdod_graph_set_param', 'sdod_graph_load_file', 'sdod_graph_finalize', 'sdod_graph_io', 'sdod_graph_execute', 'sdod_graph_check',
     'sdod_graph_stats', 'sdod_graph_tune_info', 'sdod_graph_num_ops', 'sdod_graph_op_info', 'sdod_graph_op_detail', 'sdod_graph_profile',
 ]
 
@@ -43,6 +43,7 @@ def _engine():
         lib.sdod_graph_finalize.argtypes = [P]
         lib.sdod_graph_io.argtypes = [P, I, I, ctypes.POINTER(P), ctypes.POINTER(ctypes.c_size_t)]
         lib.sdod_graph_execute.argtypes = [P, P, I]
+        lib.sdod_graph_check.argtypes = [P]
         lib.sdod_graph_stats.argtypes = [P, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(I),
                                          ctypes.POINTER(ctypes.c_double)]
         lib.sdod_graph_tune_info.argtypes = [P, ctypes.POINTER(I), ctypes.POINTER(I), ctypes.c_char_p, I]
@@ -161,6 +162,11 @@ class Graph:
         """static_unchanged: the static inputs (UNet: text context) are the same as in the previous execute()"""
         flags = (1 if use_hip_graph else 0) | (2 if static_unchanged else 0)
         check(self._lib.sdod_graph_execute(self._h, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), flags))
+
+    def check(self):
+        """raises once a launch of this device has failed in a way it could not report itself (a GroupNorm grid barrier that
+        timed out): call it after synchronising; execute() makes the same check on entry"""
+        check(self._lib.sdod_graph_check(self._h))
 
     def op_table(self):
         """[(label, flops, bytes)] for every launch of the graph"""

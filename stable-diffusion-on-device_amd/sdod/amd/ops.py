@@ -47,7 +47,8 @@ def workspace(nbytes, device, tag='default'):
 
 def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=None, alpha=1.0, out=None,
          conv=None, a2=None, bias_on_m=False, split_k=0, tile=0, time_iters=0, geglu=False, tail=None, bias2=None,
-         ln_s=None, ln_eps=1e-5, cold_scratch=None, phase=0, return_desc=False, w_scale=None, w_off=None, fixup=False):
+         ln_s=None, ln_eps=1e-5, cold_scratch=None, phase=0, return_desc=False, w_scale=None, w_off=None, fixup=False,
+         xcd=0):
     """out = act(alpha * A @ W^T + bias + row_bias) + residual.
 
     a: fp16 [M, K] (rows mode) or NHWC [N, H, W, C0] with conv=dict(stride=1|2, upsample=bool) (3x3 pad 1);
@@ -119,6 +120,7 @@ def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=N
     d.bias_on_m = 1 if bias_on_m else 0
     d.split_k = split_k
     d.tile = tile
+    d.xcd_panels = xcd        # 0 = per-shape choice; 1 / 2 / 4 / 8 = n-tile panels of the XCD-aware tile order (speed only)
     need = lib.sdod_gemm_workspace_bytes(ctypes.byref(d))
     if need:
         ws = workspace(need, a.device, 'gemm')

@@ -185,6 +185,113 @@ def test_halo_patch_tile_planning_without_a_gpu():
     assert plan(_conv_desc(2, 64, 64, 320, 320, tile=52, split=8)) == (52, 8)          # 45 slabs / 8: not chunk-granular
 
 
+# the geometries of tests/test_kernels_gpu.py::test_conv3x3_halo_patch_tiles (n, h, w, cin, cout) and its tile list
+HALO_TILES = list(range(37, 46)) + [49, 50, 51, 52]
+HALO_CASES = [(2, 64, 64, 128, 320), (2, 32, 32, 192, 160), (2, 16, 16, 256, 256), (2, 8, 8, 320, 192), (1, 8, 8, 64, 64),
+              (3, 8, 8, 128, 80), (1, 128, 128, 64, 128), (5, 16, 16, 64, 48),
+              (2, 96, 96, 64, 160), (2, 48, 48, 128, 80), (2, 24, 24, 192, 128), (1, 12, 12, 64, 200), (3, 12, 12, 128, 64)]
+
+
+def test_every_halo_tile_takes_some_geometry_of_the_gpu_test_matrix():
+    """the GPU halo tests skip a (tile, geometry) pair the tile declines; a planner regression that declined everything would
+    turn them green-by-skip.  sdod_gemm_halo_ok is the same host predicate the launch uses: every tile must take at least two
+    of the listed geometries, the 64 / 128 / 256-row tiles none of the rows-multiple-of-3 images that do not fit them"""
+    import ctypes
+    from sdod.amd import _lib
+    lib = _lib.hip()
+    takes = {t: [c for c in HALO_CASES if lib.sdod_gemm_halo_ok(ctypes.byref(_conv_desc(c[0], c[1], c[2], c[3], c[4])), t)] for t in HALO_TILES}
+    for t, cs in takes.items():
+        assert len(cs) >= 2, (t, cs)
+    assert (2, 64, 64, 128, 320) in takes[38] and (2, 64, 64, 128, 320) in takes[37]
+    assert (2, 96, 96, 64, 160) in takes[49] and (2, 96, 96, 64, 160) not in takes[38]
+    assert (2, 24, 24, 192, 128) in takes[51] and (2, 24, 24, 192, 128) in takes[52]
+    # not a halo tile / not a 3x3 stride-1 convolution: never
+    assert lib.sdod_gemm_halo_ok(ctypes.byref(_conv_desc(2, 64, 64, 128, 320)), 28) == 0
+    assert lib.sdod_gemm_halo_ok(ctypes.byref(_conv_desc(2, 64, 64, 128, 320, stride=2)), 38) == 0
+
+
+def test_xcd_panel_choice_minimises_the_bytes_the_eight_l2s_fetch():
+    """sdod_gemm_xcd_panels: panels * A + (8 / panels) * W is smallest (gemm.hip: xcd_panels / tile_of); a forced value wins"""
+    import ctypes
+    from sdod.amd import _lib
+    from sdod.amd._lib import GemmDesc
+    lib = _lib.hip()
+
+    def rows(m, n, k, tile, xcd=0):
+        d = GemmDesc()
+        d.a = d.w = d.out = 0x1000
+        d.M, d.N, d.K, d.lda, d.ldw, d.ldo = m, n, k, k, k, n
+        d.tile, d.split_k, d.xcd_panels = tile, 1, xcd
+        return d
+
+    # weight-heavy small-M Linear (16x16 level): A 1.3 MB, W 3.3 MB -> 4 panels x 2 bands: 4 A + 2 W = 11.8 MB (m-major: 27.5)
+    assert lib.sdod_gemm_xcd_panels(ctypes.byref(rows(512, 1280, 1280, 28))) == 4
+    # activation-heavy projection (64x64 level): A 5.2 MB, W 0.2 MB -> m-major, as before
+    assert lib.sdod_gemm_xcd_panels(ctypes.byref(rows(8192, 320, 320, 31))) == 1
+    # comparable operands: A 2.6 MB, W 0.8 MB over 32 x 10 tiles: 2 panels would fetch 8.5 MB against 9.2 -- not worth cutting
+    # every output row between XCDs (the choice moves only for a saving of 20 % or more)
+    assert lib.sdod_gemm_xcd_panels(ctypes.byref(rows(2048, 640, 640, 28))) == 1
+    assert lib.sdod_gemm_xcd_panels(ctypes.byref(rows(2048, 640, 640, 28, xcd=2))) == 2
+    # never more panels than n-tiles
+    assert lib.sdod_gemm_xcd_panels(ctypes.byref(rows(128, 128, 8192, 28))) <= 2
+    assert lib.sdod_gemm_xcd_panels(ctypes.byref(rows(8192, 320, 320, 31, xcd=4))) == 2   # 64x160 tile: two n-tiles only
+    assert lib.sdod_gemm_xcd_panels(ctypes.byref(rows(8192, 2560, 320, 14, xcd=4))) == 4
+    # deep convolution: the image is 0.16 MB, the weights 29 MB
+    assert lib.sdod_gemm_xcd_panels(ctypes.byref(_conv_desc(2, 8, 8, 1280, 1280, tile=42, split=5))) == 8
+
+
+def test_apanel_tile_eligibility_without_a_gpu():
+    """gemm_apanel_kernel (tiles 53..55) takes the transformer's short-K Linears whose row panel fits LDS, nothing else"""
+    import ctypes
+    from sdod.amd import _lib
+    from sdod.amd._lib import GemmDesc
+    lib = _lib.hip()
+
+    def rows(m, n, k, **kw):
+        d = GemmDesc()
+        d.a = d.w = d.out = 0x1000
+        d.M, d.N, d.K, d.lda, d.ldw, d.ldo = m, n, k, k, k, n
+        for key, v in kw.items():
+            setattr(d, key, v)
+        return d
+
+    ok = lambda d, t: lib.sdod_gemm_panel_ok(ctypes.byref(d), t)
+    assert ok(rows(8192, 2560, 320, geglu=1, ldo=1280), 53) == 1 and ok(rows(8192, 960, 320, ln=1), 53) == 1
+    assert ok(rows(2048, 5120, 640), 54) == 1 and ok(rows(512, 10240, 1280), 55) == 1
+    assert ok(rows(2048, 5120, 640), 53) == 0                        # 128 rows x 640: 160 KB panel
+    assert ok(rows(512, 10240, 1280), 54) == 0
+    assert ok(rows(8192, 320, 128), 53) == 0                         # two slabs of K: the ring kernel's business
+    assert ok(rows(8192, 2560, 320, split_k=2), 53) == 0 and ok(rows(8192, 2560, 320, wq=1), 53) == 0
+    assert ok(rows(8192, 2560, 320, bias_on_m=1), 53) == 0 and ok(rows(8192, 324, 320), 53) == 0
+    assert ok(_conv_desc(2, 64, 64, 320, 320), 53) == 0 and ok(rows(8192, 2560, 320), 28) == 0
+    t, s = ctypes.c_int(), ctypes.c_int()
+    d = rows(8192, 2560, 320, tile=53, split_k=0)
+    assert lib.sdod_gemm_plan(ctypes.byref(d), ctypes.byref(t), ctypes.byref(s)) == 0 and (t.value, s.value) == (53, 1)
+    info = (ctypes.c_int * 7)()
+    assert lib.sdod_gemm_tile_info(54, info) == 0 and list(info)[:4] == [64, 128, 2, 2] and info[5] == 3
+    assert lib.sdod_gemm_num_tiles() == 55
+
+
+def test_group_norm_workspace_layout_keeps_the_barrier_lines_out_of_reach():
+    """one grow-only workspace serves every (n, groups); the grid barrier's counter lines sit at a FIXED offset in
+    front, so the partial sums of no layout can land on the lines another layout uses"""
+    import ctypes
+    from sdod.amd import _lib
+    lib = _lib.hip()
+    offs = {}
+    for n, g in [(1, 16), (2, 32), (1, 32), (4, 32), (5, 8), (16, 32)]:
+        v = [ctypes.c_size_t() for _ in range(5)]
+        assert lib.sdod_group_norm_layout(n, g, *[ctypes.byref(x) for x in v]) == 0
+        sync, part, stats, shift, end = [x.value for x in v]
+        assert sync == 0 and part >= 26 * 128 and part % 128 == 0      # 25 counter lines + the sticky timeout word
+        assert part < stats < shift < end == lib.sdod_group_norm_workspace_bytes(n, g)
+        assert stats - part == n * 1024 * g * 2 * 4 and shift - stats == n * g * 2 * 4 and end - shift == n * g * 4
+        offs[(n, g)] = part
+    assert len(set(offs.values())) == 1                                 # the same barrier region for every layout
+    assert lib.sdod_group_norm_layout(0, 32, None, None, None, None, None) != 0
+    assert lib.sdod_group_norm_status() == 0 and lib.sdod_group_norm_clear_error() == 0   # no device: nothing to report
+
+
 def test_group_norm_path_selection_without_a_gpu():
     """sdod_group_norm_path: which kernel a shape gets; without a device there is no CU count, so the grid-barrier kernel is
     never chosen here (path 0 is covered by the GPU suite)"""
@@ -194,7 +301,7 @@ def test_group_norm_path_selection_without_a_gpu():
     assert lib.sdod_group_norm_path(2, 256, 1280, 640, 32, 0) == 1      # concat source
     assert lib.sdod_group_norm_path(1, 100, 64, 0, 32, 1) in (2, 3)     # fp32: LDS / two-pass kernels
     assert lib.sdod_group_norm_path(2, 64, 30, 0, 32, 0) == -1          # channels not divisible by groups
-    assert lib.sdod_group_norm_workspace_bytes(2, 32) >= (2 * 1024 * 32 * 2 + 2 * 32 * 3 + 32 * 26) * 4
+    assert lib.sdod_group_norm_workspace_bytes(2, 32) == (1024 + 2 * 1024 * 32 * 2 + 2 * 32 * 3) * 4
 
 
 def test_argument_checks_answer_before_any_launch():
