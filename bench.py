@@ -67,6 +67,8 @@ def kernel_symbol(label):
                 return f'gemm_kernel<{bm}, {bn}, {wm}, {wn}>', f'gemm_kernelILi{bm}ELi{bn}ELi{wm}ELi{wn}EE'
             if spec == 2:    # halo-patch 3x3 convolution
                 return f'conv_halo_kernel<{bm}, {bn}, {wm}, {wn}, {st}, false>', f'conv_halo_kernelILi{bm}ELi{bn}ELi{wm}ELi{wn}ELi{st}ELb0EE'
+            if spec == 3:    # A-panel kernel (short-K, wide-N Linears)
+                return f'gemm_apanel_kernel<{bm}, {bn}, {wm}, {wn}, {st}>', f'gemm_apanel_kernelILi{bm}ELi{bn}ELi{wm}ELi{wn}ELi{st}EE'
             return (f'gemm_glds_kernel<{bm}, {bn}, {wm}, {wn}, {st}, {"true" if spec else "false"}, false, {ksub}>',
                     f'gemm_glds_kernelILi{bm}ELi{bn}ELi{wm}ELi{wn}ELi{st}ELb{spec}ELb0ELi{ksub}EE')
     plain = {'gn_group': 'gn_group_kernel<', 'gn_group_red': 'gn_group_kernel<', 'gn_grid': 'gn_grid_kernel<', 'gn_small': 'gn_small_kernel<', 'gn_stats_apply': 'gn_stats_kernel<', 'splitk_reduce': 'splitk_reduce_kernel',
@@ -105,6 +107,10 @@ def spawn_ranks(n, argv):
         port = s.getsockname()[1]
     procs = []
     for r in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool only supports dmabuf IPC; with the legacy mode RCCL's
+        # intra-node transport set-up (and any CUDA-tensor sharing across processes) fails with `hipIpcGetMemHandle: invalid
+        # argument`.  The image exports it already; it is repeated here so that a bare `python bench.py --gpus N` from a shell
+        # that lost the variable still gives every rank the setting RCCL needs (an existing value is kept).
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=env))
@@ -212,10 +218,28 @@ def main():
         img = one_image()
     barrier()
     elapsed = time.perf_counter() - t0
+    rccl = None
     if dist is not None:
+        # what the driver needs to confirm the collective really spanned N ranks: every rank's own time and device, gathered
+        # with the collective itself (a line with world_size_seen != n_gpus, or fewer per-rank entries, is not an N-GPU run)
+        mine = torch.tensor([elapsed, float(dev_index), float(rank)], dtype=torch.float64, device=device)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        rows = [g.cpu().tolist() for g in gathered]
+        ver = None
+        try:
+            ver = '.'.join(str(v) for v in torch.cuda.nccl.version())   # RCCL reports through the NCCL API on ROCm
+        except Exception:
+            pass
+        rccl = {'backend': dist.get_backend(), 'world_size_seen': dist.get_world_size(), 'ranks_gathered': len(rows),
+                'nccl_version': ver, 'per_rank_ms': [round(1e3 * r[0] / args.steps, 3) for r in rows],
+                'per_rank_device': [int(r[1]) for r in rows], 'shared_device_rehearsal': share,
+                'hsa_enable_ipc_mode_legacy': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'),
+                'collectives_per_image': 'one broadcast of the text conditioning [2, 77, 768] fp16 (236,544 bytes) from rank 0'}
+        assert rccl['world_size_seen'] == world and sorted(int(r[2]) for r in rows) == list(range(world))
     assert img.shape == (n, 512, 512, 3) and img.dtype == torch.uint8
     log(f'timed region: {elapsed:.3f}s for {args.steps} step(s)')
 
@@ -324,6 +348,8 @@ def main():
             'roofline': roof,
             'setup_s': round(setup_s, 1),
         }
+        if rccl is not None:
+            out['rccl'] = rccl
 
         if want_cpu:
             z_gpu = pipe.sample_plms(ctx2, x_T, steps=20, guidance=7.5)

@@ -202,6 +202,12 @@ SDOD_API int sdod_group_norm_reduce_nhwc(const sdod_gn_reduce* red, const void* 
  * (+ bias_in[n]); W[n][k] <- fp16(W[n][k]*gamma[k]); s_out[n] = sum_k W'[n][k].  Used once per weight at graph build. */
 SDOD_API int sdod_ln_fold_f16(void* w, int n, int k, int ldw, const float* gamma, const float* beta, const float* bias_in,
                               float* s_out, float* t_out, void* stream);
+/* Composes two Linear layers that follow each other with nothing in between, y = P (W x + bw) + bp, into one (one-time, at
+ * graph build): c[o][k] = sum_j p[o][j] w[j][k] (fp32 accumulate, rounded to fp16 once), bias_out[o] = sum_j p[o][j] bw[j]
+ * + bp[o].  p: fp16 [n_out][ldp] (n_mid columns), w: fp16 [n_mid][ldw] (k columns), c: fp16 [n_out][ldc]; c must not alias
+ * p or w.  The UNet uses it for transformer_blocks.0.ff.net.2 -> proj_out (analyze_results.py:69-79 lists them as two ops). */
+SDOD_API int sdod_compose_linear_f16(const void* p, int ldp, const void* w, int ldw, void* c, int ldc, int n_out, int n_mid, int k,
+                                     const float* bias_w, const float* bias_p, float* bias_out, void* stream);
 /* LayerNorm over the last dim of fp16 [M][C] rows, fp32 weight/bias (either may be NULL); C % 8 == 0, C <= 3072. */
 SDOD_API int sdod_layer_norm_f16(const void* x, void* y, const float* weight, const float* bias, int m, int c,
                                  float eps, void* stream);

@@ -168,6 +168,7 @@ private:
         float alpha = 1.0f;
         bool bias_on_m = false;
         int lda = 0, ldo = 0;      // 0 = dense
+        int ldr = 0;               // row stride of `residual` (0 = the output's)
         bool geglu = false;        // fused value*gelu(gate) epilogue (weights packed PK_LINEAR_GEGLU)
         const Act* tail0 = nullptr; // conv(): 1x1-gathered tail segment sources (ResBlock skip connection)
         const Act* tail1 = nullptr;
@@ -182,6 +183,14 @@ private:
         float *s, *t;
     };
     std::vector<FoldJob> fold_jobs_;
+    // Linear o Linear composition at finalize (sdod_compose_linear_f16): the [n_out][k] block at `c` (row stride ld) holds W on
+    // entry and P . W afterwards; P is the [n_out][n_mid] block at `p` of the same matrix
+    struct ComposeJob {
+        f16* c; const f16* p; int ld, n_out, n_mid, k;
+        const float *bias_w, *bias_p;
+        float* bias_out;
+    };
+    std::vector<ComposeJob> compose_jobs_;
     std::vector<void*> derived_; // device buffers created at build time (folded LayerNorm vectors)
     void emit_gemm(sdod_gemm_desc d);
     // out[rows][N] = x[rows][K] . W^T ; W is params_[w] (or a raw fp16 [N][K] pointer through *_raw)

@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <thread>
 
 namespace sdod {
@@ -488,13 +490,16 @@ constexpr size_t kPrefetchMinBytes = (size_t)12 << 20; // weight matrices at lea
 const int kCandidates[] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, // (25, 26 spill in their epilogue only; the tuner decides)
                            37, 38, 39, 40, 41, 42, 43, 44, 45, // halo-patch convolution tiles: rejected by every other descriptor
                            46, 47, 48,
-                           49, 50, 51, 52}; // halo-patch tiles of 96 / 192 rows (image rows that are multiples of 3: config 5)
+                           49, 50, 51, 52, // halo-patch tiles of 96 / 192 rows (image rows that are multiples of 3: config 5)
+                           53, 54, 55};    // A-panel tiles (short-K wide-N Linears): rejected by every other descriptor
 
 struct ShapeKey {
-    int v[12];
-    bool operator<(const ShapeKey& o) const { return std::lexicographical_compare(v, v + 12, o.v, o.v + 12); }
+    static constexpr int kFields = 14;
+    int v[kFields];
+    bool operator<(const ShapeKey& o) const { return std::lexicographical_compare(v, v + kFields, o.v, o.v + kFields); }
 };
-// Picks come from two text files (13 integers per line: the shape key, then tile + 1000 * split_k):
+// Picks come from two text files (one shape per line: the 14 integers of the shape key, then tile + 1000 * split_k; lines of
+// the round-1/2 format -- 12 key integers, no w_in / n_img -- are still read: their convolutions were all square):
 //   * the SHIPPED table tune/gfx950.tune next to lib/ (located through dladdr): the picks for the headline shapes, made on
 //     an MI355X by tools/make_tune_cache.py and committed, so that every process -- bench, rocprofv3 passes, the C API, a
 //     service restart -- builds the SAME launch list without timing anything, and images are bit-identical across processes
@@ -517,29 +522,61 @@ std::string shipped_tune_path() {
     if (b == std::string::npos) return "";
     return lib.substr(0, b) + "/tune/gfx950.tune";
 }
-void tune_cache_read(const char* path, std::map<ShapeKey, int>& c) {
+struct TuneEntry {
+    int v;          // tile + 1000 * split_k
+    bool from_file; // read from a table (as opposed to timed by this process)
+};
+struct TuneCache { // process-wide; graphs may be built from several threads (libsdod_setup loads its models in parallel in the reference)
+    std::mutex mu;
+    std::map<ShapeKey, TuneEntry> map;
+    bool loaded = false;
+};
+void tune_cache_read(const char* path, std::map<ShapeKey, TuneEntry>& c) {
     FILE* f = std::fopen(path, "r");
     if (!f) return;
-    ShapeKey k;
-    int v;
-    for (;;) {
-        int got = 0;
-        for (int i = 0; i < 12; ++i) got += std::fscanf(f, "%d", &k.v[i]) == 1;
-        got += std::fscanf(f, "%d", &v) == 1;
-        if (got != 13) break;
+    char line[512];
+    while (std::fgets(line, sizeof line, f)) {
+        long val[ShapeKey::kFields + 2];
+        int n = 0;
+        char* cur = line;
+        while (n < ShapeKey::kFields + 2) {
+            char* endp = nullptr;
+            const long x = std::strtol(cur, &endp, 10);
+            if (endp == cur) break;
+            val[n++] = x;
+            cur = endp;
+        }
+        ShapeKey k{};
+        int v;
+        if (n == ShapeKey::kFields + 1) {
+            for (int i = 0; i < ShapeKey::kFields; ++i) k.v[i] = (int)val[i];
+            v = (int)val[ShapeKey::kFields];
+        } else if (n == 13) { // round-1/2 line: {a_mode, M, N, K, c0, c1, stride, upsample, ksize, h_in, flags, lda}: square images
+            for (int i = 0; i < 12; ++i) k.v[i] = (int)val[i];
+            k.v[12] = k.v[13] = 0;
+            if (k.v[0] == SDOD_A_CONV3X3 && k.v[9] > 0) {
+                const int ups = k.v[7] ? 1 : 0, stride = k.v[6] > 0 ? k.v[6] : 1;
+                const int ho = (k.v[9] << ups) / stride;
+                k.v[12] = k.v[9];                              // w_in = h_in
+                k.v[13] = ho > 0 ? k.v[1] / (ho * ho) : 0;     // n_img = M / (h_out * w_out)
+            }
+            v = (int)val[12];
+        } else {
+            continue;
+        }
         const int tile = v % 1000, split = v / 1000;
-        if (tile >= 1 && tile <= sdod_gemm_num_tiles() && split >= 1 && split <= 64) c[k] = v; // a stale table is re-tuned, not trusted
+        if (tile >= 1 && tile <= sdod_gemm_num_tiles() && split >= 1 && split <= 64) c[k] = TuneEntry{v, true}; // a stale table is re-tuned, not trusted
     }
     std::fclose(f);
 }
-std::map<ShapeKey, int>& tune_cache() {
-    static std::map<ShapeKey, int> c;
-    static bool loaded = false;
-    if (!loaded) {
-        loaded = true;
+TuneCache& tune_cache() {
+    static TuneCache c;
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (!c.loaded) {
+        c.loaded = true;
         const std::string shipped = shipped_tune_path();
-        if (!shipped.empty()) tune_cache_read(shipped.c_str(), c);
-        if (const char* path = tune_cache_path()) tune_cache_read(path, c);
+        if (!shipped.empty()) tune_cache_read(shipped.c_str(), c.map);
+        if (const char* path = tune_cache_path()) tune_cache_read(path, c.map);
     }
     return c;
 }
@@ -547,7 +584,7 @@ void tune_cache_append(const ShapeKey& k, int v) {
     const char* path = tune_cache_path();
     if (!path) return;
     if (FILE* f = std::fopen(path, "a")) {
-        for (int i = 0; i < 12; ++i) std::fprintf(f, "%d ", k.v[i]);
+        for (int i = 0; i < ShapeKey::kFields; ++i) std::fprintf(f, "%d ", k.v[i]);
         std::fprintf(f, "%d\n", v);
         std::fclose(f);
     }
@@ -567,8 +604,23 @@ void*& tune_scratch() {
     return p;
 }
 ShapeKey key_of(const sdod_gemm_desc& d) {
+    // w_in and n_img are part of the key: which halo-patch tiles take a convolution depends on both (halo_geometry), so two
+    // convolutions with equal M and h_in but different (n_img, w_in) must not share a pick
     return ShapeKey{{d.a_mode, d.M, d.N, d.K, d.c0, d.c1, d.stride, d.upsample, d.ksize, d.h_in,
-                     (d.residual ? 1 : 0) + (d.geglu ? 2 : 0) + 4 * d.tc0 + 16384 * d.tc1 + (d.ln ? (1 << 30) : 0) + (d.wq ? (1 << 29) : 0), d.lda}};
+                     (d.residual ? 1 : 0) + (d.geglu ? 2 : 0) + 4 * d.tc0 + 16384 * d.tc1 + (d.ln ? (1 << 30) : 0) + (d.wq ? (1 << 29) : 0), d.lda,
+                     d.a_mode == SDOD_A_CONV3X3 ? d.w_in : 0, d.a_mode == SDOD_A_CONV3X3 ? d.n_img : 0}};
+}
+// a table pick the library would refuse at launch (a halo-patch / A-panel tile that does not take this descriptor: a stale or
+// hand-edited table) is not used
+bool pick_runs(const sdod_gemm_desc& d, int v) {
+    sdod_gemm_desc c = d;
+    c.tile = v % 1000;
+    c.split_k = v / 1000;
+    int info[7] = {0};
+    if (sdod_gemm_tile_info(c.tile, info) != 0) return false;
+    if (info[5] == 2) return sdod_gemm_halo_ok(&c, c.tile) != 0;
+    if (info[5] == 3) return sdod_gemm_panel_ok(&c, c.tile) != 0;
+    return true;
 }
 } // namespace
 
@@ -601,10 +653,20 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
         d.workspace_bytes = ws_bytes_;
         d.fix_counters = std::getenv("SDOD_GEMM_FIXUP") && std::getenv("SDOD_GEMM_FIXUP")[0] == '1' ? fix_counters_ : nullptr;
         const ShapeKey key = key_of(d);
-        auto it = tune_cache().find(key);
-        if (it != tune_cache().end()) ++tune_hits_;
-        else ++tune_misses_;
-        if (it == tune_cache().end()) {
+        TuneCache& tc = tune_cache();
+        int pick = 0;
+        bool from_file = false;
+        {
+            std::lock_guard<std::mutex> lk(tc.mu);
+            auto it = tc.map.find(key);
+            if (it != tc.map.end() && pick_runs(d, it->second.v)) {
+                pick = it->second.v;
+                from_file = it->second.from_file;
+            }
+        }
+        if (pick && from_file) ++tune_hits_;
+        else ++tune_misses_; // timed by this process (now, or earlier by another graph): the launch list is not the table's
+        if (!pick) {
             int best = 0;
             float best_ms = 1e30f;
             // candidates: every tile x {heuristic split-K, half, double, none (one launch instead of two)}
@@ -642,11 +704,15 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
                     }
                 }
             }
-            it = tune_cache().emplace(key, best).first;
-            tune_cache_append(key, best);
+            {
+                std::lock_guard<std::mutex> lk(tc.mu);
+                tc.map[key] = TuneEntry{best, false};
+                tune_cache_append(key, best);
+            }
+            pick = best;
         }
-        d.tile = it->second % 1000;
-        d.split_k = it->second / 1000;
+        d.tile = pick % 1000;
+        d.split_k = pick / 1000;
     }
     const double fl = 2.0 * d.M * d.N * d.K;
     flops_ += fl;
@@ -721,7 +787,7 @@ void Graph::linear_raw(const f16* x, int rows, int K, const f16* w, int ldw, int
     if (o.bias_raw) d.bias = o.bias_raw;
     d.bias_on_m = o.bias_on_m ? 1 : 0;
     d.row_bias = o.row_bias; d.ld_row_bias = o.ld_row_bias; d.rows_per_img = o.rows_per_img;
-    d.residual = o.residual; d.ldr = d.ldo;
+    d.residual = o.residual; d.ldr = o.ldr ? o.ldr : d.ldo;
     d.act = o.act; d.alpha = o.alpha;
     if (o.geglu) {
         d.geglu = 1;
@@ -911,10 +977,22 @@ void Graph::finalize() {
     ops_.clear();
     static_ops_.clear();
     fold_jobs_.clear();
+    compose_jobs_.clear();
     flops_ = 0;
     build();
     for (const FoldJob& j : fold_jobs_)
         check_rc(sdod_ln_fold_f16(j.w, j.n, j.k, j.ldw, j.gamma, j.beta, j.bias_in, j.s, j.t, nullptr));
+    for (const ComposeJob& j : compose_jobs_) {
+        // P . W needs every row of W for every output row: compose from a copy of the W block
+        f16* tmp = nullptr;
+        SDOD_HIP_CHECK(hipMalloc((void**)&tmp, (size_t)j.n_mid * j.k * sizeof(f16)));
+        SDOD_HIP_CHECK(hipMemcpy2D(tmp, (size_t)j.k * sizeof(f16), j.c, (size_t)j.ld * sizeof(f16), (size_t)j.k * sizeof(f16), (size_t)j.n_mid,
+                                   hipMemcpyDeviceToDevice));
+        const int rc = sdod_compose_linear_f16(j.p, j.ld, tmp, j.k, j.c, j.ld, j.n_out, j.n_mid, j.k, j.bias_w, j.bias_p, j.bias_out, nullptr);
+        SDOD_HIP_CHECK(hipDeviceSynchronize());
+        (void)hipFree(tmp);
+        check_rc(rc);
+    }
     SDOD_HIP_CHECK(hipDeviceSynchronize());
     if (tune_scratch()) {
         (void)hipFree(tune_scratch());

@@ -26,6 +26,7 @@
 #include "host_util.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -461,8 +462,15 @@ __device__ unsigned long long g_stamp[8 * 8192];
         const unsigned wg_ = blockIdx.x + gridDim.x * blockIdx.z;                                           \
         if (threadIdx.x == 0 && wg_ < 8192) g_stamp[wg_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime();     \
     } while (0)
+// (the A-panel kernel stamps from the first lane of one consumer and one loader wave)
+#define STAMPW(i, w)                                                                                        \
+    do {                                                                                                    \
+        const unsigned wg_ = blockIdx.x;                                                                    \
+        if (threadIdx.x == 64u * (w) && wg_ < 8192) g_stamp[wg_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
 #define STAMP(i)
+#define STAMPW(i, w)
 #endif
 
 // 8 affine-uint8 weight codes (two dwords) -> f16x8 of (q - 128), exactly: byte b next to 0x64 is the fp16 number 1024 + b
@@ -1250,38 +1258,41 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
 
 // ------------------------------------------------------------------------------------------------
 // A-PANEL kernel: the short-K, wide-N Linear layers of the transformer blocks (to_q|to_k|to_v with N = 3C, the GEGLU
-// projection with N = 8C; K = C = 320 / 640 / 1280, LayerNorm folded in).  In the ring kernel above these are the launches
-// furthest from the matrix pipe: a 128x128 tile has 5-20 slabs of K, so a workgroup lives for ~5 slabs of main loop between
-// a prologue that waits for its first bytes and an epilogue (1 + 1.5 + 2 us around 2.5 us of loop at K = 320), and every slab
-// re-streams 16 KB of A next to 16 KB of W at the ~80 GB/s a CU's LDS-DMA path sustains -- the matrix pipe needs a 32 KB slab
-// every 0.24 us (133 GB/s).  Here
-//   * a workgroup owns a row PANEL of BM rows x the whole K (80 KB: 128 x 320, 64 x 640 or 32 x 1280 halves), fetched into LDS
-//     ONCE, and walks several consecutive n-tiles against it: per slab only the W half (BN x 128 bytes) crosses L2 -> LDS,
-//     i.e. half the bytes per MFMA, and the LayerNorm row statistics are computed once per panel instead of once per tile;
-//   * the W slabs of ALL its tiles are one continuous stream through a ring (loader waves, as above): while the consumers
-//     run the epilogue of tile j the first slabs of tile j + 1 are already landing, and no tile after the first waits for
-//     first bytes;
-//   * the epilogue goes from the accumulators straight to global memory (8-byte row segments per lane; GEGLU halves them
-//     again): no LDS staging tile, hence no workgroup barrier besides the one per slab, and the loaders never take part.
-// One barrier per slab, counted vmcnt waits (conservative by the few epilogue-vector DMAs at a tile boundary), XOR-swizzled
-// slab images and fragment reads exactly as in gemm_glds_kernel.  Rows mode, fp16 weights, no split-K.
+// projection with N = 8C; K = C = 320 / 640, LayerNorm folded in).  In the ring kernel above these are the launches furthest
+// from the matrix pipe: a 128x128 tile has 5-10 slabs of K, so a workgroup lives for a handful of slabs between a prologue
+// that waits for its first bytes and an epilogue that costs more than the loop (GEGLU at K = 320: 2.4 us of loop, 2.9 us of
+// epilogue -- 370 M lane-operations of LayerNorm fold / bias / GELU per launch, as much VALU time as there is MFMA time).  Here
+//   * a workgroup owns a row PANEL of BM rows x the whole K (80 KB: 128 x 320 or 64 x 640 halves), fetched into LDS ONCE, and
+//     walks several consecutive n-tiles against it: per slab only the W half (BN x 128 bytes) crosses L2 -> LDS, and the
+//     LayerNorm row statistics are computed once per panel instead of once per tile;
+//   * the W slabs of ALL its tiles are one continuous stream through a ring (4 loader waves, as above): no tile after the
+//     first waits for first bytes;
+//   * TWO consumer groups of 4 waves (one wave of each per SIMD) take the tiles alternately: while group X multiplies tile
+//     j + 1, group Y runs the epilogue of tile j on the SIMDs' vector pipes -- the matrix pipe never waits for an epilogue
+//     (profiles/r03_panel_phases.txt: with one group the K loops were 12 of a workgroup's 30 us);
+//   * the epilogue goes from the accumulators straight to global memory: v_permlane16_swap pairs the 4-column pieces of two
+//     lane groups into 16-byte row segments; no LDS staging tile, so the only workgroup synchronisation is the one barrier per
+//     slab -- which the group in its epilogue, and the idle group of the first tile, take part in at the same cadence (KT
+//     barriers per tile from every wave).
+// Counted vmcnt waits (conservative by the few epilogue-vector DMAs at a tile boundary), XOR-swizzled slab images and fragment
+// reads exactly as in gemm_glds_kernel.  Rows mode, fp16 weights, no split-K.
 template <int BM, int BN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(512) void gemm_apanel_kernel(const GemmP p, const f16* __restrict__ zeros) {
-    constexpr int NL = 4;                                   // loader waves (4..7); consumers are waves 0..3
+__global__ __launch_bounds__(768) void gemm_apanel_kernel(const GemmP p, const f16* __restrict__ zeros) {
+    constexpr int NL = 4;                                   // loader waves (8..11); consumer groups are waves 0..3 and 4..7
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int A_LD = BM / (8 * NL), B_LD = BN / (8 * NL);
     constexpr int AHEAD = STAGES - 1;
     constexpr int ASLAB = BM * 64, WSLAB = BN * 64;         // halves per slab of the panel / of the ring
-    static_assert(WM * WN == 4 && BM % 32 == 0 && BN % 64 == 0 && TM >= 1 && TN >= 2 && TN % 2 == 0, "tile shape");
+    static_assert(WM * WN == 4 && BM % 32 == 0 && BN % 64 == 0 && BN <= 128 && TM >= 1 && TN >= 2 && TN % 2 == 0, "tile shape");
     static_assert(B_LD * AHEAD + 2 < 64, "vmcnt is a 6-bit counter");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int KT = p.K / BK;
     f16* sAp = reinterpret_cast<f16*>(smem_raw);            // [KT][BM][64]
     f16* sW = sAp + (size_t)KT * ASLAB;                     // [STAGES][BN][64]
-    float* colv = reinterpret_cast<float*>(sW + (size_t)STAGES * WSLAB); // [2 tiles][bias | ln_s][BN]
-    float* ln_stats = colv + 4 * BN;                        // [BM][2] mean, rstd
+    float* colv = reinterpret_cast<float*>(sW + (size_t)STAGES * WSLAB); // [3 tiles][bias | ln_s][BN]
+    float* ln_stats = colv + 6 * BN;                        // [BM][2] mean, rstd
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1301,14 +1312,15 @@ __global__ __launch_bounds__(512) void gemm_apanel_kernel(const GemmP p, const f
     const int t_begin = ng * p.ap_tpg;
     const int T = min(p.tiles_n, t_begin + p.ap_tpg) - t_begin; // n-tiles of this workgroup
     if (T <= 0) return;
+    STAMPW(0, 0);
     const int m0 = pm * BM;
     const int total = T * KT;                                    // W slabs this workgroup streams
     const int lrow = lane >> 3;
     const int lchunk = (lane & 7) ^ lrow;
 
-    if (wave >= 4) {
+    if (wave >= 8) {
         // ---------------- LOADER program ----------------
-        const int lw = wave - 4;
+        const int lw = wave - 8;
         unsigned a_off[A_LD], b_off[B_LD];
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
@@ -1321,19 +1333,22 @@ __global__ __launch_bounds__(512) void gemm_apanel_kernel(const GemmP p, const f
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) lds_dma16_saddr(ab, a_off[i], sAp + (size_t)kt * ASLAB + (i * NL + lw) * 8 * 64);
         }
-        int nj = 0, nit = 0, nslot = 0; // next slab to issue: tile, K slab, ring slot
+        int nj = 0, nit = 0, nslot = 0, ncv = 0; // next slab to issue: tile, K slab, ring slot; epilogue-vector buffer of its tile
         auto issue_next = [&]() {
             const int n0 = (t_begin + nj) * BN;
             if (nit == 0) {
-                // a new tile: its per-column epilogue vectors (bias | LayerNorm-fold s) -> colv[nj & 1], older than its first slab;
-                // and the per-lane weight row offsets (rows past N clamp to the last one: they feed columns nobody stores)
+                // a new tile: its per-column epilogue vectors (bias | LayerNorm-fold s) -> colv[nj % 3], older than its first
+                // slab (three buffers: tile j's are read by its epilogue during the K loop of tile j + 1, while the loaders are
+                // already fetching those of tile j + 2); and the per-lane weight row offsets (rows past N clamp to the last one:
+                // they feed columns nobody stores)
                 const int vec = lw >> 1, q = lw & 1;
                 if (q * 64 < BN) {
                     const int n = n0 + q * 64 + lane;
                     const float* base = vec == 0 ? p.bias : (p.ln ? p.ln_s : nullptr);
                     const float* g = (base != nullptr && n < p.N) ? base + n : reinterpret_cast<const float*>(zeros) + lane;
-                    __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(colv + ((nj & 1) * 2 + vec) * BN + q * 64), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(colv + (ncv * 2 + vec) * BN + q * 64), 4, 0, 0);
                 }
+                ncv = ncv + 1 == 3 ? 0 : ncv + 1;
 #pragma unroll
                 for (int i = 0; i < B_LD; ++i) {
                     const int n = min(n0 + (i * NL + lw) * 8 + lrow, p.N - 1);
@@ -1395,14 +1410,15 @@ __global__ __launch_bounds__(512) void gemm_apanel_kernel(const GemmP p, const f
             if (g + AHEAD < total) issue_next();
         }
         wait_vmcnt<0>();
+        STAMPW(7, 8);
         return;
     }
 
-    // ---------------- CONSUMER program ----------------
-    const int cw = wave;
+    // ---------------- CONSUMER program (two groups, alternating tiles) ----------------
+    const int grp = wave >> 2, cw = wave & 3;
     const int wm = cw / WN, wn = cw % WN;
     const int frag_row = lane & 15, frag_chunk = lane >> 4;
-    const int e_m = lane & 15, e_n = (lane >> 4) * 4;
+    const int e_m = lane & 15, e_g = lane >> 4;
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     f16x8 fa[2][TM], fb[2][TN];
@@ -1441,98 +1457,152 @@ __global__ __launch_bounds__(512) void gemm_apanel_kernel(const GemmP p, const f
     };
     const float alpha = p.alpha;
     const int n_out = p.geglu ? p.N / 2 : p.N;
-    int slot = 0;
-    for (int jt = 0; jt < T; ++jt) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        __builtin_amdgcn_s_barrier(); // the tile's first slab is in LDS (the loaders waited for it); for jt = 0 so is the panel
-        __builtin_amdgcn_sched_barrier(0);
-        read_half(I0{}, I0{}, 0, slot);
-        for (int it = 0; it < KT; ++it) {
-            read_half(I1{}, I1{}, it, slot);
-            mfma_half(I0{});
-            interleave_reads_with_mfmas();
-            __builtin_amdgcn_sched_barrier(0);
-            if (it + 1 < KT) {
-                __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): my reads of this slab are done, its slot may be refilled
-                __builtin_amdgcn_s_barrier();
-                slot = slot + 1 == STAGES ? 0 : slot + 1;
-                __builtin_amdgcn_sched_barrier(0);
-                read_half(I0{}, I0{}, it + 1, slot);
-            }
-            mfma_half(I1{});
-            interleave_reads_with_mfmas();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        slot = slot + 1 == STAGES ? 0 : slot + 1;
-        // ---- epilogue of tile jt, accumulators -> global (the loaders are already streaming tile jt + 1)
+    // 4 + 4 packed halves of two lane groups -> one 16-byte row segment per lane: lane group g holds columns 4g .. 4g + 3 of
+    // 16-column blocks X and Y; after the two swaps an even group holds columns 4g .. 4g + 7 of X, an odd group columns
+    // 4(g - 1) .. 4g + 3 of Y (v_permlane16_swap: odd rows of the first operand <-> even rows of the second)
+    auto pair_store = [&](f16x4 hx, f16x4 hy, int m, int col_x, int col_y, int limit) {
+        const u32x2 ux = __builtin_bit_cast(u32x2, hx), uy = __builtin_bit_cast(u32x2, hy);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
+        const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+        const int col = (e_g & 1) ? col_y + 4 * (e_g - 1) : col_x + 4 * e_g;
+        if (m < p.M && col < limit) *reinterpret_cast<u32x4*>(p.out + (size_t)m * p.ldo + col) = v;
+    };
+    // Epilogue of tile jt from this group's accumulators, in UNITS of two 16-column blocks of one 16-row block; with BARS the
+    // group takes part in the KT slab barriers of the tile the other group is multiplying meanwhile, spread over the units.
+    auto epilogue = [&](auto bars_c, int jt, int cv) {
+        constexpr bool BARS = decltype(bars_c)::value;
         const int n0 = (t_begin + jt) * BN;
-        const float* cvb = colv + (jt & 1) * 2 * BN; // bias
-        const float* cvs = cvb + BN;                 // LayerNorm-fold s
+        const float* cvb = colv + cv * 2 * BN; // bias
+        const float* cvs = cvb + BN;           // LayerNorm-fold s
+        auto unit_done = [&](int u, int nu) {
+            if constexpr (BARS) {
+                const int nb = ((u + 1) * KT) / nu - (u * KT) / nu;
+                for (int k = 0; k < nb; ++k) __builtin_amdgcn_s_barrier();
+            }
+        };
         if (p.geglu) {
+            constexpr int NU = TM * (TN / 4 > 0 ? TN / 4 : 1);
+            static_assert(TN % 4 == 0, "GEGLU pairs two output blocks = four accumulator blocks per unit");
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int ml = wm * WTM + i * 16 + e_m, m = m0 + ml;
+                const float mean = p.ln ? ln_stats[2 * ml] : 0.f, rstd = p.ln ? ln_stats[2 * ml + 1] : 1.f;
+#pragma unroll
+                for (int j = 0; j < TN; j += 4) {
+                    f16x4 h[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int jj = j + 2 * q;
+                        const int nl = wn * WTN + jj * 16 + 4 * e_g; // column of the value block in W-row space
+                        const f32x4 ba = *reinterpret_cast<const f32x4*>(cvb + nl), bg = *reinterpret_cast<const f32x4*>(cvb + nl + 16);
+                        const f32x4 sa = *reinterpret_cast<const f32x4*>(cvs + nl), sg = *reinterpret_cast<const f32x4*>(cvs + nl + 16);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float va = acc[i][jj][r] * alpha, vg = acc[i][jj + 1][r] * alpha;
+                            if (p.ln) {
+                                va = rstd * (va - mean * sa[r]);
+                                vg = rstd * (vg - mean * sg[r]);
+                            }
+                            va += ba[r];
+                            vg += bg[r];
+                            h[q][r] = (f16)(va * gelu_erf_f(vg));
+                        }
+                    }
+                    const int c0 = (n0 + wn * WTN + j * 16) / 2;
+                    pair_store(h[0], h[1], m, c0, c0 + 16, n_out);
+                    unit_done(i * (TN / 4) + j / 4, NU);
+                }
+            }
+        } else {
+            constexpr int NU = TM * TN / 2;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int ml = wm * WTM + i * 16 + e_m, m = m0 + ml;
                 const float mean = p.ln ? ln_stats[2 * ml] : 0.f, rstd = p.ln ? ln_stats[2 * ml + 1] : 1.f;
 #pragma unroll
                 for (int j = 0; j < TN; j += 2) {
-                    const int nl = wn * WTN + j * 16 + e_n; // column of the value block in W-row space
-                    const f32x4 ba = *reinterpret_cast<const f32x4*>(cvb + nl), bg = *reinterpret_cast<const f32x4*>(cvb + nl + 16);
-                    const f32x4 sa = *reinterpret_cast<const f32x4*>(cvs + nl), sg = *reinterpret_cast<const f32x4*>(cvs + nl + 16);
-                    f16x4 h;
+                    f16x4 h[2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float va = acc[i][j][r] * alpha, vg = acc[i][j + 1][r] * alpha;
-                        if (p.ln) {
-                            va = rstd * (va - mean * sa[r]);
-                            vg = rstd * (vg - mean * sg[r]);
+                    for (int q = 0; q < 2; ++q) {
+                        const int nl = wn * WTN + (j + q) * 16 + 4 * e_g, n = n0 + nl;
+                        const f32x4 b1 = *reinterpret_cast<const f32x4*>(cvb + nl);
+                        const f32x4 sv = *reinterpret_cast<const f32x4*>(cvs + nl);
+                        f32x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float f = acc[i][j + q][r] * alpha;
+                            if (p.ln) f = rstd * (f - mean * sv[r]);
+                            v[r] = f + b1[r];
                         }
-                        va += ba[r];
-                        vg += bg[r];
-                        h[r] = (f16)(va * gelu_erf_f(vg));
-                    }
-                    const int col = (n0 + wn * WTN + j * 16) / 2 + e_n;
-                    if (m < p.M && col < n_out) *reinterpret_cast<f16x4*>(p.out + (size_t)m * p.ldo + col) = h;
-                }
-            }
-        } else {
+                        if (p.act != ACT_NONE) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int ml = wm * WTM + i * 16 + e_m, m = m0 + ml;
-                const float mean = p.ln ? ln_stats[2 * ml] : 0.f, rstd = p.ln ? ln_stats[2 * ml + 1] : 1.f;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int nl = wn * WTN + j * 16 + e_n, n = n0 + nl;
-                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(cvb + nl);
-                    const f32x4 sv = *reinterpret_cast<const f32x4*>(cvs + nl);
-                    f32x4 v;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float f = acc[i][j][r] * alpha;
-                        if (p.ln) f = rstd * (f - mean * sv[r]);
-                        f += b1[r];
-                        v[r] = f;
-                    }
-                    if (p.act != ACT_NONE) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
-                    }
-                    if (m < p.M && n < p.N) {
-                        if (p.residual != nullptr) {
+                            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+                        }
+                        if (p.residual != nullptr && m < p.M && n < p.N) {
                             const f16x4 rr = *reinterpret_cast<const f16x4*>(p.residual + (size_t)m * p.ldr + n);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = (float)(f16)v[r] + (float)rr[r];
                         }
-                        f16x4 h;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) h[r] = (f16)v[r];
-                        *reinterpret_cast<f16x4*>(p.out + (size_t)m * p.ldo + n) = h;
+                        for (int r = 0; r < 4; ++r) h[q][r] = (f16)v[r];
                     }
+                    const int c0 = n0 + wn * WTN + j * 16;
+                    pair_store(h[0], h[1], m, c0, c0 + 16, n_out);
+                    unit_done(i * (TN / 2) + j / 2, NU);
                 }
             }
         }
+    };
+
+    int slot = 0; // ring slot of the next slab (every wave tracks it through the tiles it does not multiply, too)
+    int cv = 0;   // epilogue-vector buffer of tile s
+    for (int s = 0; s < T; ++s) {
+        if ((s & 1) == grp) {
+            // ---- multiply tile s
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_s_barrier(); // the tile's first slab is in LDS (the loaders waited for it); for s = 0 so is the panel
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == 0) STAMPW(1, 0);
+            read_half(I0{}, I0{}, 0, slot);
+            for (int it = 0; it < KT; ++it) {
+                read_half(I1{}, I1{}, it, slot);
+                mfma_half(I0{});
+                interleave_reads_with_mfmas();
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + 1 < KT) {
+                    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): my reads of this slab are done, its slot may be refilled
+                    __builtin_amdgcn_s_barrier();
+                    slot = slot + 1 == STAGES ? 0 : slot + 1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_half(I0{}, I0{}, it + 1, slot);
+                }
+                mfma_half(I1{});
+                interleave_reads_with_mfmas();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            slot = slot + 1 == STAGES ? 0 : slot + 1;
+            if (s == 0) STAMPW(2, 0);
+            if (s == 2) STAMPW(4, 0);
+        } else {
+            // ---- the other group multiplies tile s: finish tile s - 1 meanwhile, meeting the KT slab barriers of tile s
+            if (s >= 1) {
+                epilogue(std::true_type{}, s - 1, cv == 0 ? 2 : cv - 1);
+                if (s == 1) STAMPW(3, 0);
+            } else {
+                for (int k = 0; k < KT; ++k) __builtin_amdgcn_s_barrier();
+            }
+            slot = (slot + KT) % STAGES;
+        }
+        cv = cv + 1 == 3 ? 0 : cv + 1;
+    }
+    if (((T - 1) & 1) == grp) {
+        if (grp == 0) STAMPW(5, 0);
+        epilogue(std::false_type{}, T - 1, cv == 0 ? 2 : cv - 1); // nobody is multiplying any more: no barriers left to meet
+        if (grp == 0) STAMPW(6, 0);
     }
 }
 
@@ -2395,16 +2465,36 @@ hipError_t launch_halo(const GemmP& p, dim3 grid, size_t smem, hipStream_t st) {
 }
 
 size_t panel_smem(int bm, int bn, int K) {
-    return (size_t)(K / BK) * bm * 128 + (size_t)kPanelStages * bn * 128 + (size_t)4 * bn * sizeof(float) + (size_t)bm * 2 * sizeof(float);
+    return (size_t)(K / BK) * bm * 128 + (size_t)kPanelStages * bn * 128 + (size_t)6 * bn * sizeof(float) + (size_t)bm * 2 * sizeof(float);
 }
 // Does A-panel tile `tile` take descriptor d?  (plain row-major fp16 operands, the epilogues of the transformer Linears)
 bool panel_ok(const sdod_gemm_desc* d, int tile) {
     if (!is_panel_tile(tile)) return false;
     if (d->a_mode != SDOD_A_ROWS || d->wq || d->k_tail || d->bias_on_m || d->row_bias || d->bias2 || d->split_k > 1) return false;
-    if (d->K % BK || d->K / BK < 3 || d->N % 8 || d->ldo % 4 || (d->geglu && d->N % 32)) return false;
-    if (d->residual && (d->geglu || d->ldr % 4)) return false;
+    if (d->K % BK || d->K / BK < 3 || d->N % 8 || d->ldo % 8 || ((uintptr_t)d->out & 15) || (d->geglu && d->N % 32)) return false;
+    if (d->residual && (d->geglu || d->ldr % 4 || ((uintptr_t)d->residual & 7))) return false;
     if ((unsigned long long)d->M * d->lda * 2 >= (1ull << 32) || (unsigned long long)d->N * d->ldw * 2 >= (1ull << 32)) return false;
     return panel_smem(kTiles[tile].bm, kTiles[tile].bn, d->K) <= 160 * 1024;
+}
+
+// n-tiles per workgroup (and groups per panel) of the A-panel kernel: whole waves of 256 workgroups (one per CU) where the
+// shape allows, and as many tiles per workgroup as that leaves -- the panel fetch (about 1.5 tiles' worth of time) is paid
+// once per workgroup
+void panel_grid(int panels, int tiles_n, int* tpg_out, int* groups_out) {
+    int best_tpg = 1;
+    double best = -1.0;
+    for (int tpg = tiles_n; tpg >= 1; --tpg) {
+        const int groups = (tiles_n + tpg - 1) / tpg;
+        const double wgs = (double)panels * groups;
+        const double eff = wgs / (std::ceil(wgs / 256.0) * 256.0);
+        const double score = eff * tpg / (tpg + 1.5);
+        if (score > best * 1.0001) {
+            best = score;
+            best_tpg = tpg;
+        }
+    }
+    *tpg_out = best_tpg;
+    *groups_out = (tiles_n + best_tpg - 1) / best_tpg;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -2417,7 +2507,7 @@ hipError_t launch_panel(const GemmP& p, dim3 grid, size_t smem, hipStream_t st) 
     }
     const f16* z = zero_line();
     if (!z) return hipErrorOutOfMemory;
-    SDOD_LAUNCH((gemm_apanel_kernel<BM, BN, WM, WN, kPanelStages>), grid, dim3(512), smem, st, p, z);
+    SDOD_LAUNCH((gemm_apanel_kernel<BM, BN, WM, WN, kPanelStages>), grid, dim3(768), smem, st, p, z);
     return hipGetLastError();
 }
 
@@ -2686,7 +2776,7 @@ extern "C" int sdod_gemm_tile_info(int tile, int out[7]) {
         {32, 64, 2, 2, 6, 1, 1}, {32, 128, 1, 4, 6, 1, 1}, {32, 160, 2, 2, 4, 1, 1},
         {96, 160, 2, 2, 3, 2, 1}, {96, 64, 2, 2, 4, 2, 1}, {192, 80, 4, 1, 4, 2, 1}, {192, 64, 4, 1, 4, 2, 1},
         // SPEC column 3 = gemm_apanel_kernel<BM, BN, WM, WN, STAGES>
-        {128, 128, 2, 2, kPanelStages, 3, 1}, {64, 128, 2, 2, kPanelStages, 3, 1}, {32, 128, 1, 4, kPanelStages, 3, 1}};
+        {128, 128, 2, 2, kPanelStages, 3, 1}, {64, 128, 2, 2, kPanelStages, 3, 1}, {32, 128, 2, 2, kPanelStages, 3, 1}};
     static_assert(sizeof(kInfo) / sizeof(kInfo[0]) == kNumTiles + 1, "one row per tile");
     if (tile < 1 || tile > kNumTiles || !out) return sdod::INVALID_ARGUMENT;
     for (int i = 0; i < 7; ++i) out[i] = kInfo[tile][i];
@@ -2849,16 +2939,14 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         SDOD_REQUIRE(panel_ok(d, pl.tile), "this A-panel tile does not take the GEMM (plain rows x fp16 weights, K >= 192, the row panel must fit LDS)");
         // grid: one workgroup per (row panel, group of consecutive n-tiles), about one per CU
         p.ap_panels = p.tiles_m;
-        int groups = std::max(1, std::min(p.tiles_n, (256 + p.ap_panels / 2) / p.ap_panels));
-        p.ap_tpg = (p.tiles_n + groups - 1) / groups;
-        p.ap_groups = (p.tiles_n + p.ap_tpg - 1) / p.ap_tpg;
+        panel_grid(p.ap_panels, p.tiles_n, &p.ap_tpg, &p.ap_groups);
         p.ap_nmajor = (double)d->N * d->K > (double)d->M * d->K ? 1 : 0; // W the bigger operand: an XCD keeps a group's W, not a panel's A
         const size_t smem = panel_smem(tc.bm, tc.bn, d->K);
         const dim3 pgrid(p.ap_panels * p.ap_groups);
         switch (pl.tile) {
         case 53: e = launch_panel<128, 128, 2, 2>(p, pgrid, smem, st); break;
         case 54: e = launch_panel<64, 128, 2, 2>(p, pgrid, smem, st); break;
-        default: e = launch_panel<32, 128, 1, 4>(p, pgrid, smem, st); break;
+        default: e = launch_panel<32, 128, 2, 2>(p, pgrid, smem, st); break;
         }
         SDOD_HIP_CHECK(e);
         return 0;

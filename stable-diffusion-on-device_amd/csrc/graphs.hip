@@ -119,8 +119,25 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     const int o2w = P(tb + ".attn2.to_out.0.weight", {C, C}, PK_LINEAR), o2b = P(tb + ".attn2.to_out.0.bias", {C}, PK_VEC);
     const int l3w = P(tb + ".norm3.weight", {C}, PK_VEC), l3b = P(tb + ".norm3.bias", {C}, PK_VEC);
     const int f1w = P(tb + ".ff.net.0.proj.weight", {8 * C, C}, PK_LINEAR_GEGLU), f1b = P(tb + ".ff.net.0.proj.bias", {8 * C}, PK_VEC_GEGLU);
-    const int f2w = P(tb + ".ff.net.2.weight", {C, 4 * C}, PK_LINEAR), f2b = P(tb + ".ff.net.2.bias", {C}, PK_VEC);
-    const int pow_ = lin ? P(pfx + ".proj_out.weight", {C, C}, PK_LINEAR) : P(pfx + ".proj_out.weight", {C, C, 1, 1}, PK_CONV1);
+    // ff.net.2 and proj_out follow each other with nothing but a residual add in between:
+    //   out = P (W2 g + b2 + t2) + bp + x = [P W2 | P] [g ; t2] + (P b2 + bp) + x
+    // so the two Linears (analyze_results.py:69-79 lists them as separate ops) are ONE GEMM over K = 5C on the row-wise concat
+    // [g | t2]: both weights live in one [C][5C] matrix whose first 4C columns are replaced by P W2 at finalize
+    // (sdod_compose_linear_f16, fp32 accumulate, one fp16 rounding), GEGLU writes g and attn2.to_out writes t2 straight into the
+    // concatenated buffer.  One launch and one [rows][C] round trip less per transformer block.  Not with uint8 weights (integer
+    // codes cannot be composed); SDOD_COMPOSE=0 keeps the two-GEMM form (A/B switch).
+    static const bool compose_on = [] { const char* e = std::getenv("SDOD_COMPOSE"); return !(e && e[0] == '0'); }();
+    const bool compose = compose_on && !quant_mode();
+    int f2w, pow_;
+    if (compose) {
+        f2w = Pc(tb + ".ff.net.2.weight", {C, 4 * C}, PK_LINEAR, 5 * C, 0, -1);
+        pow_ = lin ? Pc(pfx + ".proj_out.weight", {C, C}, PK_LINEAR, 5 * C, 4 * C, f2w)
+                   : Pc(pfx + ".proj_out.weight", {C, C, 1, 1}, PK_CONV1, 5 * C, 4 * C, f2w);
+    } else {
+        f2w = P(tb + ".ff.net.2.weight", {C, 4 * C}, PK_LINEAR);
+        pow_ = lin ? P(pfx + ".proj_out.weight", {C, C}, PK_LINEAR) : P(pfx + ".proj_out.weight", {C, C, 1, 1}, PK_CONV1);
+    }
+    const int f2b = P(tb + ".ff.net.2.bias", {C}, PK_VEC);
     const int pob = P(pfx + ".proj_out.bias", {C}, PK_VEC);
     if (mode_ == DECLARE) return act(x.n, x.h, x.w, C);
 
@@ -163,6 +180,27 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     f16* a2 = alloc((size_t)rows * C);
     attention(q2, kv, kv + C, a2, B, heads, L, Lk, d, C, kv_total_, kv_total_, C, false);
     release(q2);
+    if (compose) {
+        // [g | t2] rows of 5C: attn2.to_out writes its C columns (row stride 5C), the GEGLU projection reads them (LayerNorm
+        // folded) and writes the first 4C, the composed Linear reads all 5C
+        f16* cat = alloc((size_t)rows * 5 * C);
+        f16* t2c = cat + 4 * C;
+        { GemmOpt o; o.bias = o2b; o.residual = t1.p; o.ldr = C; o.ldo = 5 * C; linear(a2, rows, C, o2w, C, t2c, o); }
+        release(a2); release(t1);
+        { GemmOpt o; o.bias = f1b; o.geglu = true; o.ln_w = l3w; o.ln_b = l3b; o.lda = 5 * C; o.ldo = 5 * C; linear(t2c, rows, C, f1w, 8 * C, cat, o); }
+        float* bc = nullptr;
+        if (mode_ == REAL) {
+            SDOD_HIP_CHECK(hipMalloc((void**)&bc, (size_t)C * sizeof(float)));
+            derived_.push_back(bc);
+            f16* wc = reinterpret_cast<f16*>(params_[f2w].dev);
+            compose_jobs_.push_back(ComposeJob{wc, wc + 4 * C, 5 * C, C, C, 4 * C, W<float>(f2b), W<float>(pob), bc});
+        }
+        Act out = act(x.n, x.h, x.w, C);
+        { GemmOpt o; o.bias_raw = mode_ == REAL ? bc : reinterpret_cast<const float*>(params_[f2w].dev); o.residual = x.p;
+          linear_raw(cat, rows, 5 * C, reinterpret_cast<const f16*>(params_[f2w].dev), 5 * C, C, out.p, o); }
+        release(cat);
+        return out;
+    }
     Act t2 = act(B, 1, L, C);
     { GemmOpt o; o.bias = o2b; o.residual = t1.p; linear(a2, rows, C, o2w, C, t2.p, o); }
     release(a2); release(t1);

@@ -1307,7 +1307,42 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(f16* w, int N, int K, int 
     }
 }
 
+// Linear o Linear composition (one-time, at graph build): c[o][k] = sum_j p[o][j] * w[j][k] in fp32, rounded to fp16 once;
+// bias_out[o] = sum_j p[o][j] * bias_w[j] + bias_p[o].  One thread per output element; w rows are read coalesced along k.
+__global__ __launch_bounds__(256) void compose_linear_kernel(const f16* __restrict__ pmat, int ldp, const f16* __restrict__ wmat, int ldw,
+                                                             f16* __restrict__ cmat, int ldc, int n_out, int n_mid, int k,
+                                                             const float* bias_w, const float* bias_p, float* bias_out) {
+    const int kk = blockIdx.x * 256 + threadIdx.x;
+    const int o = blockIdx.y;
+    if (kk < k) {
+        float acc = 0.f;
+        const f16* prow = pmat + (size_t)o * ldp;
+        for (int j = 0; j < n_mid; ++j) acc += (float)prow[j] * (float)wmat[(size_t)j * ldw + kk];
+        cmat[(size_t)o * ldc + kk] = (f16)acc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && bias_out) {
+        float b = bias_p ? bias_p[o] : 0.f;
+        if (bias_w) {
+            const f16* prow = pmat + (size_t)o * ldp;
+            for (int j = 0; j < n_mid; ++j) b += (float)prow[j] * bias_w[j];
+        }
+        bias_out[o] = b;
+    }
+}
+
 } // namespace
+
+extern "C" int sdod_compose_linear_f16(const void* p, int ldp, const void* w, int ldw, void* c, int ldc, int n_out, int n_mid, int k,
+                                       const float* bias_w, const float* bias_p, float* bias_out, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(p && w && c && n_out > 0 && n_mid > 0 && k > 0 && ldp >= n_mid && ldw >= k && ldc >= k, "bad argument");
+    SDOD_REQUIRE(c != w && c != p, "the composed matrix must not alias its factors");
+    SDOD_LAUNCH(compose_linear_kernel, dim3((k + 255) / 256, n_out), dim3(256), 0, (hipStream_t)stream, (const f16*)p, ldp, (const f16*)w, ldw,
+                (f16*)c, ldc, n_out, n_mid, k, bias_w, bias_p, bias_out);
+    SDOD_HIP_CHECK(hipGetLastError());
+    return 0;
+    SDOD_CATCH
+}
 
 extern "C" int sdod_ln_fold_f16(void* w, int n, int k, int ldw, const float* gamma, const float* beta, const float* bias_in,
                                 float* s_out, float* t_out, void* stream) {

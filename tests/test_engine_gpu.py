@@ -143,6 +143,15 @@ def test_unet_graph_config2_full_size(unet_oracle):
     assert abs(st['flops'] / 1.607e12 - 1) < 0.02, st   # 1.607 TFLOP per batch-2 evaluation
 
 
+def test_unet_graph_config4_batch4_full_size(unet_oracle):
+    """BASELINE.json configs[3]: per-rank share of the 16-image DPM job -- 2 images per GPU = a batch-4 UNet evaluation at
+    64x64 (the M = 16384 / 4096 / 1024 / 256 GEMM shapes of tune/gfx950.tune), against the fp32 oracle"""
+    r, st = _unet_case(unet_oracle, 64, 4, 13)
+    print('unet 64x64 batch 4 rel-L2', r, st)
+    assert r <= 1e-2, r
+    assert abs(st['flops'] / (2 * 1.607e12) - 1) < 0.02, st
+
+
 def test_vae_decoder_graph(vae_oracle):
     from sdod.amd import engine as E
     cfg = E.sd14_config(16, 16)

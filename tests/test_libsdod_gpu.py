@@ -98,6 +98,54 @@ def test_generate_image_through_c_api_matches_python_loop_and_oracle(models, ora
     assert b'released' in L.libsdod_get_last_error_extra_info(1, None)
 
 
+def test_generate_image_at_the_sample_apps_size_through_c_api(models, oracle_lib, capfd):
+    """The C boundary at the size the reference's sample app runs (simple_app.cpp:9-33: 4, 64, 8, 20 -> a 512x512 image):
+    setup -> set_initial_latent -> generate, the 512^2 uint8 image against the CPU oracle of the driver loop
+    (context.cpp:292-403: DPM-Solver++(2M), reference CFG, mode-0 uint8), same tolerance as the 16x16 test above; and the
+    four phase timers the reference logs at INFO (context.cpp:331, :381, :398, :402), here from stream events"""
+    from oracle import pipeline_oracle as PO, sd_torch as S
+    from sdod.amd.host import LibSdod, Tokenizer
+    mdir, sds = models
+    prompt = 'A photograph of an astronaut riding a horse'
+    app = LibSdod(mdir + '/', latent_channels=4, latent_spatial=64, upscale_factor=8, steps=20, log_level=2, use_htp=1)
+    assert app.status == 0, app.error()
+    x_T = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(43))
+    assert app.set_initial_latent(x_T.numpy()) == 0
+    rc, img = app.generate(prompt, 7.5)            # first call: eager passes + graph capture
+    assert rc == 0, app.error(rc)
+    assert app.set_initial_latent(x_T.numpy()) == 0
+    capfd.readouterr()
+    rc, img2 = app.generate(prompt, 7.5)
+    assert rc == 0 and img.shape == (512, 512, 3) and img.dtype == np.uint8
+    assert np.array_equal(img, img2), 'same latent, same prompt: the replayed graphs must reproduce the eager image'
+    log = capfd.readouterr().out
+    import re
+    its = [float(v) for v in re.findall(r'Single iteration took ([0-9.]+)ms', log)]
+    cond = re.findall(r'Conditioning took ([0-9.]+)ms', log); dec = re.findall(r'Decoding took ([0-9.]+)ms', log)
+    tot = re.findall(r'Image generation took ([0-9.]+)ms', log)
+    assert len(its) == 20 and len(cond) == 1 and len(dec) == 1 and len(tot) == 1, log
+    print(f'C API 512x512: conditioning {cond[0]} ms, iteration median {sorted(its)[10]:.2f} ms, decoding {dec[0]} ms, image {tot[0]} ms')
+    # device-side phase times add up to (at most) the host's wall clock of the call, and decode no longer contains the sampler loop
+    assert float(cond[0]) + sum(its) + float(dec[0]) <= float(tot[0]) * 1.02 + 1.0
+    assert float(dec[0]) < 0.5 * float(tot[0]) and 1.0 < sorted(its)[10] < 50.0
+    assert app.release() == 0
+
+    tok = Tokenizer(mdir + '/ctokenizer.txt')
+    with torch.device('meta'):
+        unet, vae, clip = S.UNetModel(), S.AutoencoderKLDecode(), S.ClipTextModel()
+    unet.load_state_dict({k: v.float() for k, v in {**sds['unet'], **sds['temb']}.items()}, assign=True)
+    vae.load_state_dict({k: v.float() for k, v in sds['vae_decoder'].items()}, assign=True)
+    clip.load_state_dict({k: v.float() for k, v in sds['text_encoder'].items()}, assign=True)
+    ids = np.stack([tok.encode(''), tok.encode(prompt)]).astype(np.int64)
+    with torch.no_grad():
+        c = clip(torch.from_numpy(ids))
+    z_ref = PO.dpm_sample(unet.eval(), oracle_lib, c[0:1], c[1:2], x_T, steps=20, guidance=7.5)
+    img_ref = PO.decode_u8(vae.eval(), z_ref, mode=0, oracle_lib=oracle_lib)[0]
+    diff = np.abs(img.astype(np.int32) - img_ref.astype(np.int32))
+    print('C API 512x512 vs oracle: max diff', int(diff.max()), 'within 2 LSB', float((diff <= 2).mean()))
+    assert float((diff <= 2).mean()) >= 0.99
+
+
 def test_setup_failure_reports_through_error_table(tmp_path):
     from sdod.amd.host import LibSdod
     app = LibSdod(str(tmp_path), latent_spatial=16, steps=20)

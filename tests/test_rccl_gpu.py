@@ -39,6 +39,8 @@ dist.destroy_process_group()
 
 
 def test_rccl_backend_runs_the_conditioning_broadcast_on_device():
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the pool's host driver only supports dmabuf IPC (RCCL's transport set-up fails with
+    # `hipIpcGetMemHandle: invalid argument` otherwise); the image exports it, the test pins it
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29700 + os.getpid() % 200), HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run([sys.executable, '-c', RCCL_WORKER, ROOT], env=env, capture_output=True, text=True, timeout=600)
     print(r.stdout[-2000:], r.stderr[-2000:])
@@ -56,3 +58,8 @@ def test_bench_gpus_2_from_a_bare_shell():
     assert len(lines) == 1, r.stdout                      # rank 0 prints ONE JSON line
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0 and out['config']['global_batch'] == 2
+    # the block the driver verifies an N-rank run with: every rank's own time, gathered by the collective itself
+    rc = out['rccl']
+    assert rc['world_size_seen'] == 2 and rc['ranks_gathered'] == 2 and len(rc['per_rank_ms']) == 2 and all(t > 0 for t in rc['per_rank_ms'])
+    assert rc['backend'] == 'gloo' and rc['shared_device_rehearsal'] is True and rc['per_rank_device'] == [0, 0]
+    assert abs(max(rc['per_rank_ms']) - out['ms_per_step']) < 1e-2
