@@ -319,31 +319,54 @@ def test_argument_checks_answer_before_any_launch():
 
 
 def test_shipped_tile_table_is_well_formed():
-    """tune/gfx950.tune (the table every process builds its launch lists from): 12 key fields + pick per line, no duplicate
+    """tune/gfx950.tune (the table every process builds its launch lists from): 14 key fields + pick per line, no duplicate
     keys, tile ids the library knows, split factors in range; halo-patch picks only on 3x3 stride-1 convolutions whose
-    geometry the tile holds (sdod_gemm_plan keeps the chunk-granular plan) -- a stale or hand-edited table fails here, not on
-    the GPU box"""
+    geometry the tile holds and A-panel picks only on GEMMs the panel kernel takes (sdod_gemm_halo_ok / sdod_gemm_panel_ok on
+    a descriptor rebuilt from the key) -- a stale or hand-edited table fails here, not on the GPU box"""
     import ctypes
     import os
     from sdod.amd import _lib
+    from sdod.amd._lib import GemmDesc
     lib = _lib.hip()
     path = os.path.join(os.path.dirname(_lib.LIB_DIR), 'tune', 'gfx950.tune')
     assert os.path.exists(path), path
     ntiles = lib.sdod_gemm_num_tiles()
     seen = set()
     info = (ctypes.c_int * 7)()
-    n_halo = 0
+    n_halo = n_panel = 0
     for ln, line in enumerate(open(path), 1):
         v = line.split()
-        assert len(v) == 13, (ln, line)
+        assert len(v) == 15, (ln, line)
         v = [int(x) for x in v]
-        key = tuple(v[:12])
+        key = tuple(v[:14])
         assert key not in seen, f'duplicate key on line {ln}'
         seen.add(key)
-        tile, split = v[12] % 1000, v[12] // 1000
-        assert 1 <= tile <= ntiles and 1 <= split <= 64, (ln, v[12])
+        tile, split = v[14] % 1000, v[14] // 1000
+        assert 1 <= tile <= ntiles and 1 <= split <= 64, (ln, v[14])
         assert lib.sdod_gemm_tile_info(tile, info) == 0
-        if info[5] == 2:   # conv_halo_kernel: the key must be a 3x3 stride-1 convolution (a_mode 1, stride 1, ksize 3)
-            assert v[0] == 1 and v[6] == 1 and v[8] == 3, (ln, line)
+        a_mode, M, N, K, c0, c1, stride, ups, ksize, h_in, flags, lda, w_in, n_img = key
+        if info[5] in (2, 3):
+            d = GemmDesc()
+            d.a = d.w = d.out = 0x1000
+            d.a2 = 0x1000 if c1 else None
+            d.a_mode, d.M, d.N, d.K, d.c0, d.c1, d.stride, d.upsample, d.ksize = a_mode, M, N, K, c0, c1, stride, ups, ksize
+            d.h_in, d.w_in, d.n_img, d.lda, d.ldw = h_in, w_in, n_img, lda, K
+            d.geglu = 1 if flags & 2 else 0
+            d.ldo = N // 2 if d.geglu else N
+            d.ln = 1 if flags & (1 << 30) else 0
+            d.wq = 1 if flags & (1 << 29) else 0
+            d.tc0, d.tc1 = (flags >> 2) & 4095, (flags >> 14) & 4095
+            if d.tc0:
+                d.k_tail = K - d.tc0 - d.tc1; d.t0 = 0x1000; d.t1 = 0x1000 if d.tc1 else None
+            if flags & 1:
+                d.residual = 0x1000; d.ldr = d.ldo
+            d.tile, d.split_k = tile, split
+        if info[5] == 2:   # conv_halo_kernel: the key must be a 3x3 stride-1 convolution (a_mode 1, stride 1, ksize 3) the tile holds
+            assert a_mode == 1 and stride == 1 and ksize == 3 and w_in > 0 and n_img > 0, (ln, line)
+            assert lib.sdod_gemm_halo_ok(ctypes.byref(d), tile) == 1, (ln, line)
             n_halo += 1
-    assert len(seen) >= 600 and n_halo >= 100, (len(seen), n_halo)
+        if info[5] == 3:   # gemm_apanel_kernel
+            d.split_k = 1
+            assert a_mode == 0 and split == 1 and lib.sdod_gemm_panel_ok(ctypes.byref(d), tile) == 1, (ln, line)
+            n_panel += 1
+    assert len(seen) >= 600 and n_halo >= 100, (len(seen), n_halo, n_panel)
