@@ -30,7 +30,7 @@ import torch  # noqa: E402
 METRIC = 'images/sec + per-UNet-step ms, SD v1.4 512x512 20-step PLMS, 1/2/4/8 MI355X'
 PEAK_TFLOPS_F16 = 2500.0   # dense fp16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = 'r02_pmc_summary.json'   # committed summary of the rocprofv3 --pmc passes of this round's build
+PMC_SUMMARY = 'r03_pmc_summary.json'   # committed summary of the rocprofv3 --pmc passes of this round's build
 # "a photograph of an astronaut riding a horse" needs the CLIP vocabulary, which is absent offline: fixed ids
 IDS_COND = [49406, 320, 1125, 539, 550, 18376, 6765, 320, 4558] + [49407] * 68
 IDS_UNCOND = [49406] + [49407] * 76

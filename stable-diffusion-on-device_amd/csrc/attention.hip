@@ -44,8 +44,14 @@ constexpr int odd16(int dv) { // smallest 16*odd >= dv  (V row stride in halves:
     return s * 16;
 }
 
+// waves per SIMD the register allocation must leave room for: the d = 40 two-query-tile kernel needs 170 VGPRs left alone --
+// two over the 168 that let THREE workgroups share a CU (the kernel is issue-bound with stalls a third wave can fill:
+// SQ counters, profiles/r02_attention_sq_counters.txt); same step for d = 80 with one query tile (176)
+template <int D, int QT>
+constexpr int attn_min_waves() { return (D == 40 || (D == 80 && QT == 1)) ? 3 : 1; }
+
 template <int D, int QT, bool TR>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, (attn_min_waves<D, QT>())) void attn_kernel(const AttnP p) {
     constexpr int DP = ((D + 31) / 32) * 32; // QK^T contraction, padded to MFMA K=32
     constexpr int KSTEPS = DP / 32;
     constexpr int DV = ((D + 15) / 16) * 16; // PV output columns, padded to 16

@@ -1,9 +1,9 @@
 # Round profile set (GPU box).  Every process builds its launch lists from the shipped tune table (tune/gfx950.tune), so the
 # un-profiled bench line, the kernel trace and the three PMC passes describe ONE launch list.  The kernel trace replays the
 # trajectory graph exactly as the bench does; the PMC passes run the launch list eagerly (counters are per dispatch) and are
-# separate passes, never combined with trace domains.  usage: bash tools/run_profile.sh [tag]   (tag default r02)
+# separate passes, never combined with trace domains.  usage: bash tools/run_profile.sh [tag]   (tag default r03)
 export PYTHONUNBUFFERED=1 TMPDIR=/tmp
-TAG="${1:-r02}"
+TAG="${1:-r03}"
 O=gpurun_out/$TAG
 rm -rf $O && mkdir -p $O
 timeout -k 10 600 python3 bench.py --steps 5 --warmup 2 > $O/bench_line.json 2> $O/bench_line.err && echo "bench done" &&
