@@ -38,7 +38,7 @@ extern "C" {
 enum sdod_act { SDOD_ACT_NONE = 0, SDOD_ACT_SILU = 1, SDOD_ACT_GELU = 2, SDOD_ACT_QUICK_GELU = 3 };
 /* SDOD_U8Q (graph parameters only): per-tensor affine uint8, the reference's QNN weight format (`quantize=8`, todlc.py:108;
  * qnn_context.cpp:1018-1033): payload = {float scale; int32 offset (<= 0); uint8 q[numel]}, real = (q + offset) * scale */
-enum sdod_dtype { SDOD_F16 = 0, SDOD_F32 = 1, SDOD_U8Q = 2 };
+enum sdod_dtype { SDOD_F16 = 0, SDOD_F32 = 1, SDOD_U8Q = 2, SDOD_BF16 = 3 /* sdod_group_norm_nchw only */ };
 enum sdod_a_mode { SDOD_A_ROWS = 0, SDOD_A_CONV3X3 = 1 /* NHWC gather: 3x3 pad 1 or 1x1 */ };
 
 /* out[M][N] = act(alpha * A[M][K] . W[N][K]^T + bias + row_bias) + residual        (fp16 in/out, fp32 acc)
@@ -170,6 +170,15 @@ SDOD_API int sdod_group_norm_path(int n, int hw, int c0, int c1, int groups, int
 SDOD_API int sdod_group_norm_nhwc(const void* x, const void* x2, void* y, const float* weight, const float* bias,
                                   int n, int hw, int c0, int c1, int groups, float eps, int silu, int dtype,
                                   void* workspace, void* stream);
+
+/* The same operator on torch's default layout, NCHW "[N][C][spatial]" (what sdod.EfficientGN receives from a model that was
+ * not converted to channels_last, efficient_gn.py:61-86): a group is one contiguous slab of (C / G) * spatial elements, so
+ * there is no transpose and no constraint on C; fp16 / bf16 / fp32, y may be x.  Slabs up to 32 Ki elements take one launch
+ * (read once); bigger ones a statistics + an apply launch and `workspace` (>= sdod_group_norm_nchw_workspace_bytes(n,
+ * groups) bytes, no initialisation needed, one per stream). */
+SDOD_API size_t sdod_group_norm_nchw_workspace_bytes(int n, int groups);
+SDOD_API int sdod_group_norm_nchw(const void* x, void* y, const float* weight, const float* bias, int n, int c, long long spatial,
+                                  int groups, float eps, int silu, int dtype, void* workspace, void* stream);
 
 /* GroupNorm whose source-0 tensor is still in split-K form: the producing GEMM ran with phase = 1 (fp32 partial slabs only),
  * and this call does what its phase 2 (splitk_reduce + fused epilogue) would have done -- x = fp16(act(alpha * sum_s partial

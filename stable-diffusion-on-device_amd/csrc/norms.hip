@@ -1330,6 +1330,267 @@ __global__ __launch_bounds__(256) void compose_linear_kernel(const f16* __restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm over NCHW ("[N][C][spatial]", torch's default layout) -- the layout `sdod.EfficientGN` receives from a model that
+// was not converted to channels_last (efficient_gn.py:61-86 takes whatever the UNet hands it).  In this layout a group is ONE
+// contiguous slab of L = (C / G) * spatial elements, so the kernel needs no transpose (the NHWC kernels above would pay a
+// torch .contiguous() round trip first: twice the operator's algorithmic bytes) and no divisibility of C: any channel count,
+// fp16 / bf16 / fp32.
+//   * slabs up to 32 Ki elements: ONE launch, a 512-thread workgroup per (image, group) holds its slab in registers (read
+//     once), exact two-pass mean / variance by block reductions, normalise (+ SiLU) + store;
+//   * bigger slabs: statistics launch (grid: slabs x chunks, shifted sums, one partial per workgroup -- no atomics, fixed
+//     reduction order) + apply launch (every workgroup re-reduces the <= 64 partials of its slab).
+struct GnNchwP {
+    const void* x;
+    void* y;
+    const float* w;
+    const float* b;
+    float* partial; // [slabs][chunks][2], big-slab path only
+    int G, Cg, S;   // groups, channels per group, spatial size
+    long long L;    // Cg * S
+    int chunks;
+    long long per_chunk;
+    float eps;
+    int silu;
+};
+
+template <typename T> struct NchwIo;
+template <> struct NchwIo<f16> {
+    static SDOD_DEVICE float ld(const void* p, long long i) { return (float)reinterpret_cast<const f16*>(p)[i]; }
+    static SDOD_DEVICE void st(void* p, long long i, float v) { reinterpret_cast<f16*>(p)[i] = (f16)v; }
+    static SDOD_DEVICE void ld8(const void* p, long long i, float (&v)[8]) {
+        const f16x8 h = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16*>(p) + i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+    }
+    static SDOD_DEVICE void st8(void* p, long long i, const float (&v)[8]) {
+        f16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (f16)v[e];
+        *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p) + i) = h;
+    }
+};
+template <> struct NchwIo<float> {
+    static SDOD_DEVICE float ld(const void* p, long long i) { return reinterpret_cast<const float*>(p)[i]; }
+    static SDOD_DEVICE void st(void* p, long long i, float v) { reinterpret_cast<float*>(p)[i] = v; }
+    static SDOD_DEVICE void ld8(const void* p, long long i, float (&v)[8]) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + i);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + i + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+    static SDOD_DEVICE void st8(void* p, long long i, const float (&v)[8]) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p) + i) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p) + i + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+};
+struct bf16_tag {};
+SDOD_DEVICE float bf16_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+SDOD_DEVICE uint16_t f32_to_bf16(float v) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    // round to nearest even; a NaN stays a NaN (the integer form alone would turn some NaNs into zero or infinity)
+    return (v != v) ? (uint16_t)0x7FC0 : (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+template <> struct NchwIo<bf16_tag> {
+    static SDOD_DEVICE float ld(const void* p, long long i) { return bf16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]); }
+    static SDOD_DEVICE void st(void* p, long long i, float v) { reinterpret_cast<uint16_t*>(p)[i] = f32_to_bf16(v); }
+    static SDOD_DEVICE void ld8(const void* p, long long i, float (&v)[8]) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(p) + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = __builtin_bit_cast(float, w[e] << 16);
+            v[2 * e + 1] = __builtin_bit_cast(float, w[e] & 0xFFFF0000u);
+        }
+    }
+    static SDOD_DEVICE void st8(void* p, long long i, const float (&v)[8]) {
+        u32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p) + i) = w;
+    }
+};
+
+SDOD_DEVICE float block_sum_512(float v, float* red) { // red: >= 8 floats of LDS; every thread gets the total
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+
+// affine + SiLU + store of 8 consecutive slab elements starting at slab index i (the channel changes every S elements)
+template <typename T>
+SDOD_DEVICE void gn_nchw_finish8(const GnNchwP& p, long long base, long long i, int g, float (&v)[8], float mean, float rstd) {
+    int c = g * p.Cg + (int)(i / p.S);
+    int left = p.S - (int)(i % p.S); // elements of channel c from i on
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if (left == 0) { ++c; left = p.S; }
+        --left;
+        float f = (v[e] - mean) * rstd;
+        if (p.w) f = f * p.w[c] + p.b[c];
+        if (p.silu) f = silu_f(f);
+        v[e] = f;
+    }
+    NchwIo<T>::st8(p.y, base + i, v);
+}
+
+// VEC = the slab is a whole number of 16-byte (fp32: 32-byte) vectors and so aligned: 8 elements per thread and step
+template <typename T, int KMAX, bool VEC>
+__global__ __launch_bounds__(512) void gn_nchw_one_kernel(const GnNchwP p) {
+    __shared__ float red[8];
+    const long long slab = blockIdx.x; // n * G + g
+    const int g = (int)(slab % p.G);
+    const long long base = slab * p.L;
+    constexpr int W = VEC ? 8 : 1;
+    float v[KMAX][W];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const long long i = ((long long)k * 512 + threadIdx.x) * W;
+        if constexpr (VEC) {
+            if (i < p.L) NchwIo<T>::ld8(p.x, base + i, v[k]);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+        } else {
+            v[k][0] = i < p.L ? NchwIo<T>::ld(p.x, base + i) : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < W; ++e) sum += v[k][e];
+    }
+    const float mean = block_sum_512(sum, red) / (float)p.L;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const long long i = ((long long)k * 512 + threadIdx.x) * W;
+        if (i < p.L) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const float d = v[k][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(block_sum_512(sq, red) / (float)p.L + p.eps);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const long long i = ((long long)k * 512 + threadIdx.x) * W;
+        if (i < p.L) {
+            if constexpr (VEC) {
+                gn_nchw_finish8<T>(p, base, i, g, v[k], mean, rstd);
+            } else {
+                const int c = g * p.Cg + (int)(i / p.S);
+                float f = (v[k][0] - mean) * rstd;
+                if (p.w) f = f * p.w[c] + p.b[c];
+                if (p.silu) f = silu_f(f);
+                NchwIo<T>::st(p.y, base + i, f);
+            }
+        }
+    }
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(512) void gn_nchw_stats_kernel(const GnNchwP p) {
+    __shared__ float red[8];
+    const long long slab = blockIdx.y;
+    const long long base = slab * p.L;
+    const long long i0 = (long long)blockIdx.x * p.per_chunk, i1 = min(p.L, i0 + p.per_chunk);
+    const float shift = NchwIo<T>::ld(p.x, base); // pilot: the slab's first element (shifted sums keep fp32 accurate)
+    float s1 = 0.f, s2 = 0.f;
+    if constexpr (VEC) { // per_chunk is a multiple of 8
+        for (long long i = i0 + (long long)threadIdx.x * 8; i < i1; i += 512 * 8) {
+            float v[8];
+            NchwIo<T>::ld8(p.x, base + i, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[e] - shift;
+                s1 += d;
+                s2 += d * d;
+            }
+        }
+    } else {
+        for (long long i = i0 + threadIdx.x; i < i1; i += 512) {
+            const float d = NchwIo<T>::ld(p.x, base + i) - shift;
+            s1 += d;
+            s2 += d * d;
+        }
+    }
+    s1 = block_sum_512(s1, red);
+    s2 = block_sum_512(s2, red);
+    if (threadIdx.x == 0) {
+        float* dst = p.partial + (slab * p.chunks + blockIdx.x) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
+    }
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(512) void gn_nchw_apply_kernel(const GnNchwP p) {
+    const long long slab = blockIdx.y;
+    const int g = (int)(slab % p.G);
+    const long long base = slab * p.L;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < p.chunks; ++c) { // every thread, same order: bit-reproducible
+        const float* src = p.partial + (slab * p.chunks + c) * 2;
+        s1 += src[0];
+        s2 += src[1];
+    }
+    const float shift = NchwIo<T>::ld(p.x, base);
+    const float md = s1 / (float)p.L;
+    float var = s2 / (float)p.L - md * md;
+    var = var < 0.f ? 0.f : var;
+    const float mean = shift + md, rstd = 1.0f / sqrtf(var + p.eps);
+    const long long i0 = (long long)blockIdx.x * p.per_chunk, i1 = min(p.L, i0 + p.per_chunk);
+    if constexpr (VEC) {
+        for (long long i = i0 + (long long)threadIdx.x * 8; i < i1; i += 512 * 8) {
+            float v[8];
+            NchwIo<T>::ld8(p.x, base + i, v);
+            gn_nchw_finish8<T>(p, base, i, g, v, mean, rstd);
+        }
+    } else {
+        for (long long i = i0 + threadIdx.x; i < i1; i += 512) {
+            const int c = g * p.Cg + (int)(i / p.S);
+            float f = (NchwIo<T>::ld(p.x, base + i) - mean) * rstd;
+            if (p.w) f = f * p.w[c] + p.b[c];
+            if (p.silu) f = silu_f(f);
+            NchwIo<T>::st(p.y, base + i, f);
+        }
+    }
+}
+
+template <typename T, bool VEC>
+static void gn_nchw_launch_v(const GnNchwP& p, long long slabs, hipStream_t st) {
+    constexpr int W = VEC ? 8 : 1;
+    if (p.L <= 512 * 64) {
+        const int k = (int)((p.L + 512 * W - 1) / (512 * W));
+        if (k <= 1) SDOD_LAUNCH((gn_nchw_one_kernel<T, 1, VEC>), dim3((unsigned)slabs), dim3(512), 0, st, p);
+        else if (k <= 2) SDOD_LAUNCH((gn_nchw_one_kernel<T, 2, VEC>), dim3((unsigned)slabs), dim3(512), 0, st, p);
+        else if (k <= 4) SDOD_LAUNCH((gn_nchw_one_kernel<T, 4, VEC>), dim3((unsigned)slabs), dim3(512), 0, st, p);
+        else if (k <= 8) SDOD_LAUNCH((gn_nchw_one_kernel<T, 8, VEC>), dim3((unsigned)slabs), dim3(512), 0, st, p);
+        else if constexpr (!VEC) {
+            if (k <= 16) SDOD_LAUNCH((gn_nchw_one_kernel<T, 16, VEC>), dim3((unsigned)slabs), dim3(512), 0, st, p);
+            else if (k <= 32) SDOD_LAUNCH((gn_nchw_one_kernel<T, 32, VEC>), dim3((unsigned)slabs), dim3(512), 0, st, p);
+            else SDOD_LAUNCH((gn_nchw_one_kernel<T, 64, VEC>), dim3((unsigned)slabs), dim3(512), 0, st, p);
+        }
+        SDOD_HIP_CHECK(hipGetLastError());
+        return;
+    }
+    SDOD_LAUNCH((gn_nchw_stats_kernel<T, VEC>), dim3(p.chunks, (unsigned)slabs), dim3(512), 0, st, p);
+    SDOD_HIP_CHECK(hipGetLastError());
+    SDOD_LAUNCH((gn_nchw_apply_kernel<T, VEC>), dim3(p.chunks, (unsigned)slabs), dim3(512), 0, st, p);
+    SDOD_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+static void gn_nchw_launch(const GnNchwP& p, long long slabs, bool vec, hipStream_t st) {
+    if (vec) gn_nchw_launch_v<T, true>(p, slabs, st);
+    else gn_nchw_launch_v<T, false>(p, slabs, st);
+}
+
 } // namespace
 
 extern "C" int sdod_compose_linear_f16(const void* p, int ldp, const void* w, int ldw, void* c, int ldc, int n_out, int n_mid, int k,
@@ -1478,6 +1739,48 @@ extern "C" int sdod_group_norm_nhwc(const void* x, const void* x2, void* y, cons
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SDOD_F16) gn_launch<f16>(p, st);
     else gn_launch<float>(p, st);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" size_t sdod_group_norm_nchw_workspace_bytes(int n, int groups) {
+    if (n <= 0 || groups <= 0) return 0;
+    return (size_t)n * groups * 64 * 2 * sizeof(float);
+}
+
+extern "C" int sdod_group_norm_nchw(const void* x, void* y, const float* weight, const float* bias, int n, int c, long long spatial,
+                                    int groups, float eps, int silu, int dtype, void* workspace, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(x && y, "null pointer");
+    SDOD_REQUIRE(n > 0 && c > 0 && spatial > 0 && groups > 0, "bad shape");
+    SDOD_REQUIRE(c % groups == 0, "num_channels must be divisible by num_groups");
+    SDOD_REQUIRE((weight == nullptr) == (bias == nullptr), "weight and bias must both be given or both be null");
+    SDOD_REQUIRE(dtype == SDOD_F16 || dtype == SDOD_F32 || dtype == SDOD_BF16, "dtype must be SDOD_F16, SDOD_F32 or SDOD_BF16");
+    SDOD_REQUIRE((long long)n * groups < (1ll << 31) / 64, "too many (image, group) slabs");
+    GnNchwP p{};
+    p.x = x; p.y = y; p.w = weight; p.b = bias;
+    p.G = groups; p.Cg = c / groups;
+    SDOD_REQUIRE(spatial < (1ll << 31), "spatial size must fit 31 bits");
+    p.S = (int)spatial;
+    p.L = (long long)p.Cg * spatial;
+    p.eps = eps; p.silu = silu;
+    const long long slabs = (long long)n * groups;
+    if (p.L > 512 * 64) {
+        SDOD_REQUIRE(workspace != nullptr, "slabs above 32 Ki elements need the workspace (sdod_group_norm_nchw_workspace_bytes)");
+        // enough workgroups to cover the chip (~1024), at least 16 Ki elements each, at most 64 chunks per slab
+        long long chunks = std::min<long long>(64, std::max<long long>(1, (1024 + slabs - 1) / slabs));
+        chunks = std::min<long long>(chunks, std::max<long long>(1, p.L / 16384));
+        p.per_chunk = ((p.L + chunks - 1) / chunks + 7) / 8 * 8; // whole vectors per chunk
+        p.chunks = (int)((p.L + p.per_chunk - 1) / p.per_chunk);
+        p.partial = (float*)workspace;
+    }
+    // whole, aligned 8-element vectors: every slab then starts on a 16-byte (fp32: 32-byte) boundary
+    const size_t elem = dtype == SDOD_F32 ? 4 : 2;
+    const bool vec = p.L % 8 == 0 && ((uintptr_t)x % (8 * elem)) == 0 && ((uintptr_t)y % (8 * elem)) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SDOD_F16) gn_nchw_launch<f16>(p, slabs, vec, st);
+    else if (dtype == SDOD_F32) gn_nchw_launch<float>(p, slabs, vec, st);
+    else gn_nchw_launch<bf16_tag>(p, slabs, vec, st);
     return 0;
     SDOD_CATCH
 }

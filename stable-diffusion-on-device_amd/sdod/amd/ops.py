@@ -188,15 +188,34 @@ def group_norm_nhwc(x, groups, weight=None, bias=None, eps=1e-5, silu=False, x2=
     return out
 
 
+_NCHW_DTYPES = {torch.float16: 0, torch.float32: 1, torch.bfloat16: 3}
+
+
 def group_norm_nchw(x, groups, weight=None, bias=None, eps=1e-5, silu=False):
-    """torch-semantics entry used by sdod.EfficientGN: x is [N, C, *]; returns a tensor of the same logical
-    shape (channels_last strides).  The permute to NHWC is a view when x is already channels_last."""
-    if x.dtype not in (torch.float16, torch.float32):
-        raise TypeError('EfficientGN HIP kernel supports float16 and float32')
+    """torch-semantics entry used by sdod.EfficientGN: x is [N, C, *] fp16 / bf16 / fp32; returns a tensor of the same shape
+    and memory format.  No layout copy on either side: a channels_last tensor whose channel count the NHWC kernels take IS
+    their layout (the permute is a view); anything else that is dense goes to the NCHW kernel, where a group is one contiguous
+    slab (any channel count); only a tensor that is neither is made contiguous first."""
+    if x.dtype not in _NCHW_DTYPES:
+        raise TypeError('EfficientGN HIP kernels support float16, bfloat16 and float32')
     n, c = x.shape[0], x.shape[1]
-    xl = x.detach().reshape(n, c, -1).permute(0, 2, 1).contiguous()  # [N, S, C]
-    y = group_norm_nhwc(xl, groups, weight, bias, eps, silu)
-    return y.permute(0, 2, 1).reshape(x.shape)
+    x = x.detach()
+    if (x.dim() == 4 and c % 8 == 0 and x.dtype != torch.bfloat16 and not x.is_contiguous()
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        y = group_norm_nhwc(x.permute(0, 2, 3, 1), groups, weight, bias, eps, silu)     # [N, H, W, C] view -> NHWC kernels
+        return y.permute(0, 3, 1, 2)                                                      # logical NCHW, channels_last strides
+    lib = _lib.hip()
+    if not x.is_contiguous():
+        x = x.contiguous()
+    _req(x, None, 'x')
+    out = torch.empty_like(x)
+    if weight is not None:
+        weight = weight.detach().to(torch.float32).contiguous(); bias = bias.detach().to(torch.float32).contiguous()
+    spatial = x.numel() // (n * c)
+    ws = workspace(lib.sdod_group_norm_nchw_workspace_bytes(n, groups), x.device, 'gn_nchw')
+    check(lib.sdod_group_norm_nchw(_p(x), _p(out), _p(weight), _p(bias), n, c, spatial, groups, eps, 1 if silu else 0,
+                                   _NCHW_DTYPES[x.dtype], _p(ws), _stream()))
+    return out
 
 
 def ln_fold(w, gamma, beta, bias=None):

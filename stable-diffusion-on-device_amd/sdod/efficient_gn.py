@@ -11,8 +11,10 @@ What differs, on purpose:
     csrc/sdod_ops/config/group_norm.{xml,json} but never ships.  If the HIP library is missing this
     raises -- there is no silent fallback on a GPU tensor.  CPU tensors (ONNX export, CPU tests) use
     F.group_norm exactly as the reference's forward does (:11-12).
-    Shapes / dtypes outside the kernel's domain (channels not a multiple of 8, more than 4096 channels, bf16 / fp64)
-    take F.group_norm on the device, as the reference's forward would -- a stated domain limit, not an error fallback.
+    NCHW-contiguous inputs (torch's default) run the NCHW kernel (sdod_group_norm_nchw: a group is one contiguous slab --
+    no transpose, any channel count, fp16 / bf16 / fp32); channels_last fp16 / fp32 inputs with C % 8 == 0 run the NHWC
+    kernels the UNet graph uses, as a view.  Only fp64 and empty tensors take F.group_norm on the device, as the
+    reference's forward would -- a stated domain limit, not an error fallback.
   * impl='ln'/'bn' reproduce the reference bit for bit by default, INCLUDING its quirk Q1: the affine parameters are not
     applied (:84-85 has that code commented out, so the reference's own tests/gn_to_ln.py prints False for them; pinned by
     tests/golden/gn_efficient.npz), and 'bn' divides by sqrt(1 + eps) without normalising (eval-mode batch_norm against
@@ -29,9 +31,8 @@ import torch.nn.functional as F
 
 def _hip_group_norm(x, num_groups, weight, bias, eps, silu=False):
     from .amd import ops  # raises loudly if lib/libsdod.so is not built
-    c = x.shape[1]
-    if x.dtype not in (torch.float16, torch.float32) or c % 8 != 0 or c > 4096 or x.numel() == 0:
-        y = F.group_norm(x, num_groups, weight, bias, eps)       # outside the kernel's domain (see module docstring)
+    if x.dtype not in (torch.float16, torch.bfloat16, torch.float32) or x.numel() == 0:
+        y = F.group_norm(x, num_groups, weight, bias, eps)       # fp64 / empty: outside the kernels' domain (see module docstring)
         return F.silu(y) if silu else y
     return ops.group_norm_nchw(x, num_groups, weight, bias, eps, silu)
 

@@ -750,6 +750,60 @@ def test_group_norm_concat_sources():
     check(out, ref, name='gn concat')
 
 
+@pytest.mark.parametrize('shape,groups,dtype,silu,affine', [
+    ((2, 320, 64, 64), 32, torch.float16, True, True),      # UNet 64x64 map, torch's default layout: slab of 40,960 -> statistics + apply
+    ((2, 1280, 8, 8), 32, torch.float16, False, True),      # one launch, slab in registers, 16-byte vectors
+    ((1, 30, 7, 5), 3, torch.float16, True, True),          # nothing divides anything: scalar path, channels not a multiple of 8
+    ((2, 128, 128, 128), 32, torch.float32, True, False),   # fp32, 65,536-element slabs, no affine parameters
+    ((3, 64, 16, 16), 8, torch.bfloat16, False, True),      # bf16
+    ((2, 96, 1000), 4, torch.float16, True, True),          # [N, C, L] input, 24,000-element slabs
+    ((1, 8, 300, 301), 2, torch.float16, False, True),      # 361,200-element slabs that are not whole vectors per chunk
+    ((2, 4104, 4, 4), 8, torch.float32, False, True),       # more than 4096 channels
+])
+def test_group_norm_nchw_kernel(shape, groups, dtype, silu, affine):
+    """sdod_group_norm_nchw: the operator on torch's default layout (a group = one contiguous slab): no transpose, any
+    channel count, fp16 / bf16 / fp32, in place; against F.group_norm in fp32 on the same rounded inputs"""
+    from sdod.amd import ops
+    g = torch.Generator().manual_seed(hash(shape) % 1000)
+    x = (torch.randn(shape, generator=g) * 1.7 + torch.randn((shape[0], shape[1]) + (1,) * (len(shape) - 2), generator=g)).to(dtype)
+    c = shape[1]
+    w = 1 + 0.2 * torch.randn(c, generator=g) if affine else None
+    b = 0.3 * torch.randn(c, generator=g) if affine else None
+    ref = F.group_norm(x.float(), groups, w, b, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    d = dev()
+    xd = x.to(d)
+    out = ops.group_norm_nchw(xd, groups, w.to(d) if affine else None, b.to(d) if affine else None, 1e-5, silu)
+    assert out.shape == x.shape and out.dtype == dtype and out.is_contiguous()
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    check(out, ref, tol=tol, name=f'gn nchw {shape} {dtype}')
+    again = ops.group_norm_nchw(xd, groups, w.to(d) if affine else None, b.to(d) if affine else None, 1e-5, silu)
+    assert torch.equal(again, out)
+
+
+def test_efficient_gn_takes_either_layout_without_a_copy_path_difference():
+    """sdod.EfficientGN(impl='eff'): an NCHW-contiguous tensor runs the NCHW kernel, the same values in channels_last run the
+    NHWC kernels as a view; both agree with nn.GroupNorm, keep their memory format, and bf16 / odd channel counts are HIP too"""
+    import sdod
+    d = dev()
+    g = torch.Generator().manual_seed(91)
+    x = (torch.randn(2, 320, 32, 32, generator=g) * 2 + 0.5).half()
+    m = sdod.EfficientGN(32, 320, impl='eff').to(d).half()
+    with torch.no_grad():
+        m.weight.copy_(1 + 0.1 * torch.randn(320, generator=g)); m.bias.copy_(0.1 * torch.randn(320, generator=g))
+        ref = F.group_norm(x.float(), 32, m.weight.float().cpu(), m.bias.float().cpu(), 1e-5)
+        y0 = m(x.to(d))
+        y1 = m(x.to(d).contiguous(memory_format=torch.channels_last))
+    assert y0.is_contiguous() and y1.is_contiguous(memory_format=torch.channels_last)
+    check(y0, ref, name='EfficientGN nchw'); check(y1, ref, name='EfficientGN channels_last')
+    m2 = sdod.EfficientGN(5, 35, impl='eff').to(d).to(torch.bfloat16)
+    x2 = torch.randn(2, 35, 9, 9, generator=g).to(torch.bfloat16)
+    with torch.no_grad():
+        y2 = m2(x2.to(d))
+    check(y2, F.group_norm(x2.float(), 5, None, None, 1e-5), tol=1e-2, name='EfficientGN bf16, 35 channels')
+
+
 def test_efficient_gn_module_matches_reference_golden(golden_dir):
     """sdod.EfficientGN(impl='eff') on the GPU vs outputs of the reference's own module (tests/golden/gn_efficient.npz,
     generated by oracle/gen_golden.py from /root/reference/sdod/efficient_gn.py)."""
