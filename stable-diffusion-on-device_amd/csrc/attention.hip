@@ -21,6 +21,7 @@
 #include "host_util.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -49,6 +50,15 @@ constexpr int odd16(int dv) { // smallest 16*odd >= dv  (V row stride in halves:
 // SQ counters, profiles/r02_attention_sq_counters.txt); same step for d = 80 with one query tile (176)
 template <int D, int QT>
 constexpr int attn_min_waves() { return (D == 40 || (D == 80 && QT == 1)) ? 3 : 1; }
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <int N, int I = 0, class F>
+SDOD_DEVICE void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
 
 template <int D, int QT, bool TR>
 __global__ __launch_bounds__(256, (attn_min_waves<D, QT>())) void attn_kernel(const AttnP p) {
@@ -186,53 +196,131 @@ __global__ __launch_bounds__(256, (attn_min_waves<D, QT>())) void attn_kernel(co
         for (int dt = 0; dt < NDT; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    if (NT > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
-    __syncthreads();
-
 #ifdef SDOD_ATTN_ABLATE
     constexpr int abl = SDOD_ATTN_ABLATE; // developer builds only (make lib/libsdod_attnabl<mask>.so): 1 = no K/V loads after tile 0,
 #else                                     // 2 = no exp in the softmax; results are wrong, only the timing is of interest
     constexpr int abl = 0;
 #endif
-    for (int t = 0; t < NT; ++t) {
-        const int cur = t & 1;
-        const bool has_next = t + 1 < NT;
-
-        const f16* sK = smem + cur * STAGE;
-        const f16* sV = sK + KT * KSTR;
-
-        // ---- fragments of the tile first: K for S^T = K . Q^T and (transposed) V for O^T += V^T . P^T are read ONCE and kept
-        // in registers for both query tiles; the V reads are issued here so that they land during the softmax
-        // (D = 160 would need 160 registers for them and drop to one wave per SIMD: it reads at the point of use)
-        constexpr bool HOLD = D <= 80;
-        f16x8 kf[HOLD ? KSTEPS : 1][4];
-        if (HOLD) {
+    constexpr bool HOLD = D <= 80; // K / V^T fragments of a tile are read once and kept for both query tiles (d = 160: read at the point of use)
+    auto read_vt = [&](const f16* sV, int u, int dt) -> f16x8 {
+        const f16* a0 = sV + (32 * u + 4 * g + (li >> 2)) * VSTR + dt * 16 + 4 * (li & 3);
+        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(a0));
+        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(a0 + 16 * VSTR));
+        typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
+        const short8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(f16x8, both);
+    };
+    // ---- online softmax of query tile A against key tile t (scores in s_a) and O^T += V^T . P^T; lane owns query qrow[A],
+    // keys t*64 + c*16 + 4g + r.  VALU budget matters here (at d=40 the MFMAs of a tile take ~450 cycles, a naive softmax 3x
+    // that): the row max is taken on the RAW scores (scale > 0), exp2(s*c - m*c) is one fma + one v_exp, masking code only
+    // runs for tiles that contain masked keys (the last ragged tile / the causal diagonal), sums and scaling use packed fp32.
+    auto softmax_pv = [&](auto a_c, int t, f32x4 (&s_a)[4], const f16x8 (&vfr)[HOLD ? 2 : 1][HOLD ? NDT : 1], const f16* sV) {
+        constexpr int a = decltype(a_c)::value;
+        const bool need_mask = (t * KT + KT > p.Lk) || (p.causal && (t * KT + KT - 1 > q_block + wave * (16 * QT)));
+        if (need_mask) {
+            // (key0 goes through an opaque statement so that the sixteen key indices are computed INSIDE this rarely taken
+            // branch: the compiler otherwise hoists them in front of it and every tile pays for them)
+            int key0 = t * KT + g * 4;
+            asm volatile("" : "+v"(key0));
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + c * 16 + r;
+                    const bool masked = (key >= p.Lk) | (p.causal & (key > qrow[a]));
+                    s_a[c][r] = masked ? -1e30f : s_a[c][r];
+                }
+        }
+        // row maximum of this lane's 16 scores as a chain of three-input maxima (v_max3_f32: 8 instructions instead of 15)
+        float mx = fmaxf(fmaxf(s_a[0][0], s_a[0][1]), s_a[0][2]);
+        mx = fmaxf(fmaxf(mx, s_a[0][3]), s_a[1][0]);
+#pragma unroll
+        for (int c = 1; c < 4; ++c) {
+            mx = fmaxf(fmaxf(mx, s_a[c][1]), s_a[c][2]);
+            if (c < 3) mx = fmaxf(fmaxf(mx, s_a[c][3]), s_a[c + 1][0]);
+            else mx = fmaxf(mx, s_a[c][3]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run[a], mx * p.scale_log2); // running max in scaled (log2) units
+        // once the running maxima have settled (a few tiles in) no lane of the wave changes its maximum: skip the
+        // rescale of the output accumulators (wave-uniform branch)
+        const bool rescale = __builtin_amdgcn_ballot_w64(m_new != m_run[a]) != 0;
+        const float alpha = rescale ? __builtin_amdgcn_exp2f(m_run[a] - m_new) : 1.0f;
+        m_run[a] = m_new;
+        f32x2 rs2 = {0.f, 0.f};
+        const f32x2 sc2 = {p.scale_log2, p.scale_log2};
+        const f32x2 nm2 = {-m_new, -m_new};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                f32x2 v = {s_a[c][2 * h2], s_a[c][2 * h2 + 1]};
+                v = v * sc2 + nm2; // packed fma
+                if (!(abl & 2)) {
+                    v[0] = __builtin_amdgcn_exp2f(v[0]);
+                    v[1] = __builtin_amdgcn_exp2f(v[1]);
+                }
+                if (!SUM_BY_MFMA) rs2 += v;
+                s_a[c][2 * h2] = v[0];
+                s_a[c][2 * h2 + 1] = v[1];
+            }
+        }
+        if (!SUM_BY_MFMA) l_run[a] = l_run[a] * alpha + (rs2[0] + rs2[1]);
+        if (rescale) {
+            const f32x2 al2 = {alpha, alpha};
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                f32x2 lo = {o[a][dt][0], o[a][dt][1]}, hi = {o[a][dt][2], o[a][dt][3]};
+                lo *= al2; hi *= al2;
+                o[a][dt][0] = lo[0]; o[a][dt][1] = lo[1]; o[a][dt][2] = hi[0]; o[a][dt][3] = hi[1];
+            }
+        }
+        f16x8 pf[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f16x8 f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f[r] = (f16)s_a[2 * u][r];
+                f[4 + r] = (f16)s_a[2 * u + 1][r];
+            }
+            pf[u] = f;
+        }
+        // ---- O^T += V^T . P^T for this query tile; contraction element e of lane group g is key 32u + 16(e>>2) + 4g + (e&3)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                f16x8 vf;
+                if (TR) {
+                    vf = HOLD ? vfr[u][dt] : read_vt(sV, u, dt);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vf[e] = sV[(32 * u + 16 * (e >> 2) + 4 * g + (e & 3)) * VSTR + dt * 16 + li];
+                }
+                o[a][dt] = mfma16(vf, pf[u], o[a][dt]);
+            }
+        }
+    };
+    auto read_k = [&](const f16* sK, f16x8 (&kf)[HOLD ? KSTEPS : 1][4]) {
+        if constexpr (HOLD) {
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) kf[ks][c] = *reinterpret_cast<const f16x8*>(sK + (c * 16 + li) * KSTR + ks * 32 + g * 8);
         }
-        f16x8 vfr[HOLD ? 2 : 1][HOLD ? NDT : 1];
-        auto read_vt = [&](int u, int dt) -> f16x8 {
-            const f16* a0 = sV + (32 * u + 4 * g + (li >> 2)) * VSTR + dt * 16 + 4 * (li & 3);
-            const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(a0));
-            const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(a0 + 16 * VSTR));
-            typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
-            const short8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            return __builtin_bit_cast(f16x8, both);
-        };
-        if (TR && HOLD) {
+    };
+    auto read_v = [&](const f16* sV, f16x8 (&vfr)[HOLD ? 2 : 1][HOLD ? NDT : 1]) {
+        if constexpr (TR && HOLD) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) vfr[u][dt] = read_vt(u, dt);
+                for (int dt = 0; dt < NDT; ++dt) vfr[u][dt] = read_vt(sV, u, dt);
         }
-        // ---- S^T = K . Q^T, query tile by query tile: the softmax of tile a starts (VALU) while the matrix pipe is still
-        // busy with tile a + 1, and further down the PV product of tile a runs under the softmax of tile a + 1
-        f32x4 s[QT][4];
+    };
+    // S^T = K . Q^T of one key tile for every query tile of the wave
+    auto qk = [&](const f16* sK, const f16x8 (&kf)[HOLD ? KSTEPS : 1][4], f32x4 (&s)[QT][4]) {
 #pragma unroll
         for (int a = 0; a < QT; ++a) {
 #pragma unroll
@@ -245,106 +333,38 @@ __global__ __launch_bounds__(256, (attn_min_waves<D, QT>())) void attn_kernel(co
                     s[a][c] = mfma16(k8, qf[a][ks], s[a][c]);
                 }
         }
+    };
+
+    // (Round 3 tried a software-pipelined form of this loop -- the scores of tile t + 1 computed under the softmax of tile t,
+    // three LDS stages, K fragments read behind the previous barrier: 220 VGPRs, 8 % SLOWER (123 vs 113 us at 4096^2, d = 40:
+    // the compiler serialises the longer body no better, and the third LDS stage costs occupancy where B >= 4 would have
+    // used it).  Removed; profiles/r03_attention_occupancy.txt keeps the numbers.)
+    if (NT > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < NT; ++t) {
+        const int cur = t & 1;
+        const bool has_next = t + 1 < NT;
+        const f16* sK = smem + cur * STAGE;
+        const f16* sV = sK + KT * KSTR;
+        // ---- fragments of the tile first: K for S^T = K . Q^T and (transposed) V for O^T += V^T . P^T are read ONCE and kept
+        // in registers for both query tiles; the V reads are issued here so that they land during the softmax
+        // (D = 160 would need 160 registers for them and drop to one wave per SIMD: it reads at the point of use)
+        f16x8 kf[HOLD ? KSTEPS : 1][4];
+        f16x8 vfr[HOLD ? 2 : 1][HOLD ? NDT : 1];
+        read_k(sK, kf);
+        read_v(sV, vfr);
+        // ---- S^T = K . Q^T, query tile by query tile: the softmax of tile a starts (VALU) while the matrix pipe is still
+        // busy with tile a + 1, and further down the PV product of tile a runs under the softmax of tile a + 1
+        f32x4 s[QT][4];
+        qk(sK, kf, s);
         // the next tile's K/V are requested HERE, behind the fragment reads and the QK^T issue: requested at the top of the
         // iteration, the compiler's wait-count pass (it cannot count loads under divergent predicates) put a vmcnt(0) in front
         // of the first MFMA, i.e. the full global-load latency on the critical path of every tile
         if (has_next && !(abl & 1)) load_tile(t + 1);
-
-        // ---- online softmax; lane owns query qrow[a], keys t*64 + c*16 + 4g + r.
-        // VALU budget matters here (at d=40 the MFMAs of a tile take ~450 cycles, a naive softmax 3x that): the row max is
-        // taken on the RAW scores (scale > 0), exp2(s*c - m*c) is one fma + one v_exp, masking code only runs for tiles that
-        // contain masked keys (the last ragged tile / the causal diagonal), sums and scaling use packed fp32 pairs.
-        const bool need_mask = (t * KT + KT > p.Lk) || (p.causal && (t * KT + KT - 1 > q_block + wave * (16 * QT)));
-        f16x8 pf[QT][2];
-#pragma unroll
-        for (int a = 0; a < QT; ++a) {
-            if (need_mask) {
-                // (key0 goes through an opaque statement so that the sixteen key indices are computed INSIDE this rarely taken
-                // branch: the compiler otherwise hoists them in front of it and every tile pays for them)
-                int key0 = t * KT + g * 4;
-                asm volatile("" : "+v"(key0));
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = key0 + c * 16 + r;
-                        const bool masked = (key >= p.Lk) | (p.causal & (key > qrow[a]));
-                        s[a][c][r] = masked ? -1e30f : s[a][c][r];
-                    }
-            }
-            // row maximum of this lane's 16 scores as a chain of three-input maxima (v_max3_f32: 8 instructions instead of 15)
-            float mx = fmaxf(fmaxf(s[a][0][0], s[a][0][1]), s[a][0][2]);
-            mx = fmaxf(fmaxf(mx, s[a][0][3]), s[a][1][0]);
-#pragma unroll
-            for (int c = 1; c < 4; ++c) {
-                mx = fmaxf(fmaxf(mx, s[a][c][1]), s[a][c][2]);
-                if (c < 3) mx = fmaxf(fmaxf(mx, s[a][c][3]), s[a][c + 1][0]);
-                else mx = fmaxf(mx, s[a][c][3]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[a], mx * p.scale_log2); // running max in scaled (log2) units
-            // once the running maxima have settled (a few tiles in) no lane of the wave changes its maximum: skip the
-            // rescale of the output accumulators (wave-uniform branch)
-            const bool rescale = __builtin_amdgcn_ballot_w64(m_new != m_run[a]) != 0;
-            const float alpha = rescale ? __builtin_amdgcn_exp2f(m_run[a] - m_new) : 1.0f;
-            m_run[a] = m_new;
-            f32x2 rs2 = {0.f, 0.f};
-            const f32x2 sc2 = {p.scale_log2, p.scale_log2};
-            const f32x2 nm2 = {-m_new, -m_new};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    f32x2 v = {s[a][c][2 * h2], s[a][c][2 * h2 + 1]};
-                    v = v * sc2 + nm2; // packed fma
-                    if (!(abl & 2)) {
-                        v[0] = __builtin_amdgcn_exp2f(v[0]);
-                        v[1] = __builtin_amdgcn_exp2f(v[1]);
-                    }
-                    if (!SUM_BY_MFMA) rs2 += v;
-                    s[a][c][2 * h2] = v[0];
-                    s[a][c][2 * h2 + 1] = v[1];
-                }
-            }
-            if (!SUM_BY_MFMA) l_run[a] = l_run[a] * alpha + (rs2[0] + rs2[1]);
-            if (rescale) {
-                const f32x2 al2 = {alpha, alpha};
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    f32x2 lo = {o[a][dt][0], o[a][dt][1]}, hi = {o[a][dt][2], o[a][dt][3]};
-                    lo *= al2; hi *= al2;
-                    o[a][dt][0] = lo[0]; o[a][dt][1] = lo[1]; o[a][dt][2] = hi[0]; o[a][dt][3] = hi[1];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                f16x8 f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    f[r] = (f16)s[a][2 * u][r];
-                    f[4 + r] = (f16)s[a][2 * u + 1][r];
-                }
-                pf[a][u] = f;
-            }
-            // ---- O^T += V^T . P^T for this query tile; contraction element e of lane group g is key 32u + 16(e>>2) + 4g + (e&3)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    f16x8 vf;
-                    if (TR) {
-                        vf = HOLD ? vfr[u][dt] : read_vt(u, dt);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) vf[e] = sV[(32 * u + 16 * (e >> 2) + 4 * g + (e & 3)) * VSTR + dt * 16 + li];
-                    }
-                    o[a][dt] = mfma16(vf, pf[a][u], o[a][dt]);
-                }
-            }
-        }
-
-
+        static_for<QT>([&](auto a_c) { softmax_pv(a_c, t, s[decltype(a_c)::value], vfr, sV); });
         if (has_next) store_tile(cur ^ 1);
         __syncthreads();
     }
