@@ -875,8 +875,11 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                     wait_younger<LOADS, (STAGES - 2) * KSUB>(max(0, nkt - it - KSUB));
                     __builtin_amdgcn_s_barrier(); // ... and everybody's; the previous group is no longer read
                 }
-                if (p.ln) ln_accumulate(smem + (it % NSLOT) * STAGE);
+                // the next slab's DMA first, the LayerNorm-fold statistics of this one behind it: they read slot it % NSLOT, the DMA
+                // fills the slot the consumers have just left -- and the loop is paced by how early the DMA goes out, not by them
+                // (the statistics in front cost the LayerNorm-folded Linears 1-2.5 us each: profiles/r03_ln_fold_order.txt)
                 if (it + AHEAD < nkt) issue_tile(kt_begin + it + AHEAD, (it + AHEAD) % NSLOT);
+                if (p.ln) ln_accumulate(smem + (it % NSLOT) * STAGE);
             }
             wait_vmcnt<0>();
             __syncthreads();
