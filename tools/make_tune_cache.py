@@ -19,18 +19,22 @@ out = os.path.abspath(sys.argv[1])
 quick = '--quick' in sys.argv
 only_quant = '--only-quant' in sys.argv   # keep the shipped picks of every fp16 shape, re-time the uint8-weight shapes only
 only_rows3 = '--only-rows3' in sys.argv   # re-time only the 3x3 stride-1 convolutions on images whose rows are multiples of 3 (config 5)
+only_ln = '--only-ln' in sys.argv         # keep every shipped pick but those of the LayerNorm-folded Linears (key flag bit 30): re-time those
 if os.path.exists(out):
     os.remove(out)
 os.makedirs(os.path.dirname(out), exist_ok=True)
-if only_quant or only_rows3:
+if only_quant or only_rows3 or only_ln:
     shipped = os.path.join(ROOT, 'stable-diffusion-on-device_amd', 'tune', 'gfx950.tune')
     with open(shipped) as f, open(out, 'w') as g:
         for line in f:
             v = line.split()
-            if len(v) != 13:
+            if len(v) not in (13, 15):
                 continue
-            # key fields (engine.hip: key_of): 0 a_mode, 6 stride, 8 ksize, 9 h_in, 10 flags (bit 29 = uint8 weights)
-            drop = (int(v[10]) & (1 << 29)) if only_quant else (v[0] == '1' and v[6] == '1' and v[8] == '3' and int(v[9]) % 3 == 0)
+            # key fields (engine.hip: key_of): 0 a_mode, 6 stride, 8 ksize, 9 h_in, 10 flags (bit 29 = uint8 weights, bit 30 = LayerNorm fold)
+            if only_ln:
+                drop = int(v[10]) & (1 << 30)
+            else:
+                drop = (int(v[10]) & (1 << 29)) if only_quant else (v[0] == '1' and v[6] == '1' and v[8] == '3' and int(v[9]) % 3 == 0)
             if not drop:
                 g.write(line)
 os.environ['SDOD_TUNE_CACHE'] = out
@@ -60,6 +64,18 @@ if only_quant:
         build(E.UNet, cq, 2, 2100, f'sd21 unet {hw}x{hw} b2, uint8 weights', quant=True)
         build(E.Temb, cq, 1, 2101, 'sd21 temb b1, uint8 weights', quant=True)
         build(E.Temb, cq, 20, 2101, 'sd21 temb b20, uint8 weights', quant=True)
+    print(f'done: {out}')
+    sys.exit(0)
+
+if only_ln:
+    c64 = E.sd14_config(64, 64)
+    for b in (2, 4, 1):
+        build(E.UNet, c64, b, 1234, f'sd14 unet 64x64 b{b}')
+    build(E.UNet, E.sd21_config(96, 96), 2, 2100, 'sd21 unet 96x96 b2')
+    c16 = E.sd14_config(16, 16)
+    for b in (2, 4, 1):
+        build(E.UNet, c16, b, 1234, f'sd14 unet 16x16 b{b}')
+    build(E.UNet, E.sd21_config(24, 24), 2, 2100, 'sd21 unet 24x24 b2')
     print(f'done: {out}')
     sys.exit(0)
 
