@@ -86,7 +86,6 @@ struct GemmP {
     // logical ids walk panel after panel, m-major inside a panel.  xg = 1 is the plain m-major order.
     // A-panel kernel (gemm_apanel_kernel): workgroup = (row panel, group of ap_tpg consecutive n-tiles); ap_groups groups per panel
     int ap_groups, ap_tpg, ap_panels, ap_nmajor;
-    int w_nt;                // weight slabs are fetched with the non-temporal policy (big, read-once weight matrices)
     int xg_w, xg_big;        // narrow panel width; ids below xg_big belong to the wide panels
     int xg_s1, xg_s0;        // tiles per wide / narrow panel (tiles_m * width)
     int xg_nbig;             // n-tiles covered by the wide panels
@@ -431,15 +430,12 @@ SDOD_DEVICE void lds_dma16_saddr(const void* base, unsigned off, f16* lds_dst) {
     const unsigned a = (unsigned)(uintptr_t)(lds_void_ptr)lds_dst;
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(a) : "memory", "m0");
 }
-// the same with the non-temporal cache policy: for weight bytes that are read once per evaluation and arrive from HBM anyway
-// (the UNet's 1.7 GB of weights sweep the 256 MiB Infinity Cache several times per evaluation; MI355X_MICROARCH.md, nt-weights)
-SDOD_DEVICE void lds_dma16_saddr_nt(const void* base, unsigned off, f16* lds_dst) {
-    const unsigned a = (unsigned)(uintptr_t)(lds_void_ptr)lds_dst;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(off), "s"(base), "s"(a) : "memory", "m0");
-}
-SDOD_DEVICE void lds_dma16_w(bool nt, const void* base, unsigned off, f16* lds_dst) { // nt is wave-uniform
-    if (nt) lds_dma16_saddr_nt(base, off, lds_dst);
-    else lds_dma16_saddr(base, off, lds_dst);
+// (Round 3 measured the non-temporal cache policy for the weight slabs -- `global_load_lds_dwordx4 ... nt` for matrices of
+// >= 4 / 16 MiB, MI355X_MICROARCH.md nt-weights -- at +1.3 % per evaluation (profiles/r03_nt_weights.txt); the switch is gone
+// again because even switched off its wave-uniform branch sat between the barrier and every weight DMA of the loaders.)
+// The same with the LDS destination given as a byte address (running pointers of the lean loader loop).
+SDOD_DEVICE void lds_dma16_saddr_raw(const void* base, unsigned off, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_byte_addr) : "memory", "m0");
 }
 
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
@@ -671,7 +667,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
             for (int i = 0; i < A_LD; ++i) lds_dma16_saddr(ab, a_off[i], sA + (i * NL + lw) * 8 * 64);
 #pragma unroll
             for (int i = 0; i < B_LD; ++i)
-                if (!WQ || lane < 32) lds_dma16_w(p.w_nt != 0, wb, b_off[i], sB + (i * NL + lw) * 8 * 64);
+                if (!WQ || lane < 32) lds_dma16_saddr(wb, b_off[i], sB + (i * NL + lw) * 8 * 64);
             return;
         }
         if (p.k_tail && k0 >= p.k_tail) {
@@ -865,6 +861,40 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
             else setup_rows();
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) rs1[i] = rs2[i] = 0.f;
+            if (lean) {
+                // Lean loop (every Linear): the operand pointers and the LDS address of the slab to issue are RUNNING scalars,
+                // advanced behind the issue, so that between the barrier and the DMA instructions of the next slab there is
+                // nothing but the instructions themselves (the generic form recomputes k0 -> 64-bit pointers -> slot address there:
+                // ~12 scalar instructions per slab on the path that paces a short-K loop)
+                constexpr unsigned SLAB_BYTES = (unsigned)STAGE * 2u, RING_BYTES_U = (unsigned)NSLOT * SLAB_BYTES;
+                const unsigned smem_base = (unsigned)(uintptr_t)(lds_void_ptr)smem;
+                const unsigned a_dst0 = smem_base + (unsigned)(lw * 8 * 64) * 2u, b_dst0 = a_dst0 + (unsigned)(BM * 64) * 2u;
+                const char* a_ptr = reinterpret_cast<const char*>(p.a0) + (size_t)kt_begin * BK * 2;
+                const char* w_ptr = reinterpret_cast<const char*>(p.w) + (size_t)kt_begin * BK * (WQ ? 1 : 2);
+                unsigned slot_off = 0;
+                auto issue_lean = [&]() {
+#pragma unroll
+                    for (int i = 0; i < A_LD; ++i) lds_dma16_saddr_raw(a_ptr, a_off[i], a_dst0 + slot_off + (unsigned)(i * NL * 8 * 64) * 2u);
+#pragma unroll
+                    for (int i = 0; i < B_LD; ++i)
+                        if (!WQ || lane < 32) lds_dma16_saddr_raw(w_ptr, b_off[i], b_dst0 + slot_off + (unsigned)(i * NL * 8 * 64) * 2u);
+                    a_ptr += BK * 2;
+                    w_ptr += BK * (WQ ? 1 : 2);
+                    slot_off = slot_off + SLAB_BYTES == RING_BYTES_U ? 0u : slot_off + SLAB_BYTES;
+                };
+#pragma unroll
+                for (int s = 0; s < AHEAD; ++s)
+                    if (s < nkt) issue_lean();
+                STAMP(1);
+                for (int it = 0; it < nkt; ++it) {
+                    if (it % KSUB == 0) {
+                        wait_younger<LOADS, (STAGES - 2) * KSUB>(max(0, nkt - it - KSUB));
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    if (it + AHEAD < nkt) issue_lean();
+                    if (p.ln) ln_accumulate(smem + (it % NSLOT) * STAGE);
+                }
+            } else {
 #pragma unroll
             for (int s = 0; s < AHEAD; ++s)
                 if (s < nkt) issue_tile(kt_begin + s, s);
@@ -880,6 +910,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                 // (the statistics in front cost the LayerNorm-folded Linears 1-2.5 us each: profiles/r03_ln_fold_order.txt)
                 if (it + AHEAD < nkt) issue_tile(kt_begin + it + AHEAD, (it + AHEAD) % NSLOT);
                 if (p.ln) ln_accumulate(smem + (it % NSLOT) * STAGE);
+            }
             }
             wait_vmcnt<0>();
             __syncthreads();
@@ -1806,7 +1837,6 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
                 }
             }
             const unsigned char* w_s = sgpr_pin(reinterpret_cast<const unsigned char*>(p.w));
-            const bool w_nt = sgpr_pin(p.w_nt) != 0;
             constexpr int WB = WQ ? 1 : 2; // bytes per weight
             if (!tail_wg) {
                 constexpr int SLOT = BN * 64;
@@ -1886,7 +1916,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
                         f16* sB = smem + s_slot * SLOT;
 #pragma unroll
                         for (int i = 0; i < CNT; ++i)
-                            if (!WQ || lane < 32) lds_dma16_w(w_nt, w_s + (size_t)k0 * WB, b_off[i], sB + (i * NL + lw) * 8 * 64);
+                            if (!WQ || lane < 32) lds_dma16_saddr(w_s + (size_t)k0 * WB, b_off[i], sB + (i * NL + lw) * 8 * 64);
                         k0 += t == 8 ? BK - 8 * cin_s : cin_s;
                         s_slot = s_slot + 1 == STAGES ? 0 : s_slot + 1;
                     });
@@ -2932,15 +2962,6 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     make_magic((unsigned)(p.h_out * p.w_out), &p.mg_hw, &p.sh_hw);
     make_magic((unsigned)p.w_out, &p.mg_w, &p.sh_w);
     make_magic((unsigned)p.tiles_n, &p.mg_tn, &p.sh_tn);
-    {
-        // SDOD_W_NT=<MiB>: weight matrices of at least that size are streamed with the non-temporal policy (0 / unset = never)
-        static const double nt_min_bytes = [] {
-            const char* e = std::getenv("SDOD_W_NT");
-            const double mib = e ? std::atof(e) : 0.0;
-            return mib > 0.0 ? mib * 1048576.0 : 1e300;
-        }();
-        p.w_nt = (double)d->N * d->K * (d->wq ? 1.0 : 2.0) >= nt_min_bytes ? 1 : 0;
-    }
     {
         const int xg = xcd_panels(d, p.tiles_m, p.tiles_n);
         const int w = p.tiles_n / xg, r = p.tiles_n % xg;
