@@ -31,20 +31,21 @@ SDOD_DEVICE f16x8 ldg8(const f16* p) { return *reinterpret_cast<const f16x8*>(p)
 SDOD_DEVICE void stg8(f16* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }
 
 SDOD_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, two orders below fp16 resolution): one rcp, one exp, six fma --
-// the library erff is ~40 instructions with branches, and the GEGLU epilogue evaluates it 10.5 M times per ff GEMM
-SDOD_DEVICE float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
-    float poly = 1.061405429f;
-    poly = poly * t - 1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t - 0.284496736f;
-    poly = poly * t + 0.254829592f;
-    const float r = 1.0f - poly * t * __expf(-ax * ax);
-    return copysignf(r, x);
+// GELU(x) = x * Phi(x) = max(x, 0) - |x| * Q(|x|) with Q(t) = erfc(t / sqrt 2) / 2 = 2^-P(t): -log2 Q is smooth (~ t^2 / (2 ln 2)
+// + log2 t), so a degree-5 polynomial with P(0) = 1 (weighted minimax fit of the error of |x| * Q on [0, 6], monotone beyond)
+// gives |error| <= 5.4e-7 over all x, three orders below fp16 resolution -- five fma, one v_exp_f32, one max and one fma.
+// (Until round 3: erf by Abramowitz & Stegun 7.1.26, |error| <= 2.2e-7, with an rcp AND an exp: 23 issue slots against these
+// 11; the GEGLU epilogue evaluates it 10.5 M times per ff GEMM and was VALU-bound on it.  The library erff is ~40 instructions.)
+SDOD_DEVICE float gelu_erf_f(float x) {
+    const float a = fabsf(x);
+    float q = 0.000488102092f;
+    q = fmaf(q, a, -0.0071987181f); // (the library is built with -ffp-contract=off: fma where fma is meant)
+    q = fmaf(q, a, 0.052146631f);
+    q = fmaf(q, a, 0.459595845f);
+    q = fmaf(q, a, 1.15100054f);
+    q = fmaf(q, a, 1.0f);
+    return fmaf(-a, __builtin_amdgcn_exp2f(-q), fmaxf(x, 0.0f));
 }
-SDOD_DEVICE float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 SDOD_DEVICE float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_QUICK_GELU = 3 };

@@ -1166,16 +1166,12 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                     f16x4 h;
                     const f32x4 ba = *reinterpret_cast<const f32x4*>(colv + nl), bg = *reinterpret_cast<const f32x4*>(colv + nl + 16);
                     const f32x4 sa = *reinterpret_cast<const f32x4*>(colv + 2 * BN + nl), sg = *reinterpret_cast<const f32x4*>(colv + 2 * BN + nl + 16);
-                    const float mean = p.ln ? ln_stats[2 * ml] : 0.f, rstd = p.ln ? ln_stats[2 * ml + 1] : 1.f;
+                    // rstd * (alpha * acc - mean * s) + b as two fma: acc * (rstd * alpha) + (b - rstd * mean * s)
+                    const float ra = p.ln ? ln_stats[2 * ml + 1] * p.alpha : p.alpha, mr = p.ln ? -ln_stats[2 * ml + 1] * ln_stats[2 * ml] : 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float va = acc[i][j][r] * p.alpha, vg = acc[i][j + 1][r] * p.alpha;
-                        if (p.ln) {
-                            va = rstd * (va - mean * sa[r]);
-                            vg = rstd * (vg - mean * sg[r]);
-                        }
-                        va += ba[r];
-                        vg += bg[r];
+                        const float va = fmaf(acc[i][j][r], ra, p.ln ? fmaf(mr, sa[r], ba[r]) : ba[r]); // (the s vectors exist only with ln)
+                        const float vg = fmaf(acc[i][j + 1][r], ra, p.ln ? fmaf(mr, sg[r], bg[r]) : bg[r]);
                         h[r] = (f16)(va * gelu_erf_f(vg));
                     }
                     *reinterpret_cast<f16x4*>(sC + ml * SC + (wn * WTN + j * 16) / 2 + e_n) = h;
@@ -1532,7 +1528,8 @@ __global__ __launch_bounds__(768) void gemm_apanel_kernel(const GemmP p, const f
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int ml = wm * WTM + i * 16 + e_m, m = m0 + ml;
-                const float mean = p.ln ? ln_stats[2 * ml] : 0.f, rstd = p.ln ? ln_stats[2 * ml + 1] : 1.f;
+                // rstd * (alpha * acc - mean * s) + b as two fma: acc * (rstd * alpha) + (b - rstd * mean * s)
+                const float ra = p.ln ? ln_stats[2 * ml + 1] * alpha : alpha, mr = p.ln ? -ln_stats[2 * ml + 1] * ln_stats[2 * ml] : 0.f;
 #pragma unroll
                 for (int j = 0; j < TN; j += 4) {
                     f16x4 h[2];
@@ -1544,13 +1541,8 @@ __global__ __launch_bounds__(768) void gemm_apanel_kernel(const GemmP p, const f
                         const f32x4 sa = *reinterpret_cast<const f32x4*>(cvs + nl), sg = *reinterpret_cast<const f32x4*>(cvs + nl + 16);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float va = acc[i][jj][r] * alpha, vg = acc[i][jj + 1][r] * alpha;
-                            if (p.ln) {
-                                va = rstd * (va - mean * sa[r]);
-                                vg = rstd * (vg - mean * sg[r]);
-                            }
-                            va += ba[r];
-                            vg += bg[r];
+                            const float va = fmaf(acc[i][jj][r], ra, p.ln ? fmaf(mr, sa[r], ba[r]) : ba[r]);
+                            const float vg = fmaf(acc[i][jj + 1][r], ra, p.ln ? fmaf(mr, sg[r], bg[r]) : bg[r]);
                             h[q][r] = (f16)(va * gelu_erf_f(vg));
                         }
                     }
