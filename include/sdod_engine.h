@@ -69,7 +69,12 @@ typedef struct sdod_model_config {
                           * HBM (half the weight footprint and stream, BASELINE config 5 "int8 weight quant (mirrors QNN quant
                           * path)"): the GEMM expands the codes on the fragment read (sdod_gemm_desc.wq).  Costs two fusions the
                           * fp16 build has: LayerNorm is a launch again (its gamma cannot be folded into integer codes) and the
-                          * ResBlock skip 1x1 conv is its own GEMM (its tensor has its own scale / offset). */
+                          * ResBlock skip 1x1 conv is its own GEMM (its tensor has its own scale / offset).
+                          * 2 ("where it pays"): same checkpoint format, but the codes are streamed only by the blocks whose GEMMs
+                          * have <= 128 rows; every other block's tensors are dequantised once at load and the block is built
+                          * exactly as with weight_quant = 0.  On MI355X no GEMM of the UNet is weight-bandwidth bound at batch 2,
+                          * so the uint8 kernels lose wherever there are >= 288 rows and tie at 72
+                          * (profiles/r03_config5_op_tables.txt): this is the setting that is never slower than fp16. */
 } sdod_model_config;
 
 SDOD_API void sdod_model_config_sd14(sdod_model_config* cfg);

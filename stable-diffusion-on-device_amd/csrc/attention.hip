@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, (attn_min_waves<D, QT>())) void attn_kernel(co
     // ---- online softmax of query tile A against key tile t (scores in s_a) and O^T += V^T . P^T; lane owns query qrow[A],
     // keys t*64 + c*16 + 4g + r.  VALU budget matters here (at d=40 the MFMAs of a tile take ~450 cycles, a naive softmax 3x
     // that): the row max is taken on the RAW scores (scale > 0), exp2(s*c - m*c) is one fma + one v_exp, masking code only
-    // runs for tiles that contain masked keys (the last ragged tile / the causal diagonal), sums and scaling use packed fp32.
+    // runs for tiles that contain masked keys (the last ragged tile / the causal diagonal).
     auto softmax_pv = [&](auto a_c, int t, f32x4 (&s_a)[4], const f16x8 (&vfr)[HOLD ? 2 : 1][HOLD ? NDT : 1], const f16* sV) {
         constexpr int a = decltype(a_c)::value;
         const bool need_mask = (t * KT + KT > p.Lk) || (p.causal && (t * KT + KT - 1 > q_block + wave * (16 * QT)));
@@ -248,33 +248,27 @@ __global__ __launch_bounds__(256, (attn_min_waves<D, QT>())) void attn_kernel(co
         const bool rescale = __builtin_amdgcn_ballot_w64(m_new != m_run[a]) != 0;
         const float alpha = rescale ? __builtin_amdgcn_exp2f(m_run[a] - m_new) : 1.0f;
         m_run[a] = m_new;
-        f32x2 rs2 = {0.f, 0.f};
-        const f32x2 sc2 = {p.scale_log2, p.scale_log2};
-        const f32x2 nm2 = {-m_new, -m_new};
+        // plain fp32 fma / add, NOT the packed forms: beside MFMAs a v_pk_add_f32 / v_pk_fma_f32 costs several times the issue
+        // cycles of the two scalar instructions it replaces (MI355X_MICROARCH.md, per-instruction constants: an anti-lever), and
+        // this loop is bound by the SIMD's vector issue (-ffp-contract=off: the fma is spelled out)
+        float rs[4] = {0.f, 0.f, 0.f, 0.f};
+        const float sc = p.scale_log2, nm = -m_new;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                f32x2 v = {s_a[c][2 * h2], s_a[c][2 * h2 + 1]};
-                v = v * sc2 + nm2; // packed fma
-                if (!(abl & 2)) {
-                    v[0] = __builtin_amdgcn_exp2f(v[0]);
-                    v[1] = __builtin_amdgcn_exp2f(v[1]);
-                }
-                if (!SUM_BY_MFMA) rs2 += v;
-                s_a[c][2 * h2] = v[0];
-                s_a[c][2 * h2 + 1] = v[1];
+            for (int r = 0; r < 4; ++r) {
+                float v = __builtin_fmaf(s_a[c][r], sc, nm);
+                if (!(abl & 2)) v = __builtin_amdgcn_exp2f(v);
+                if (!SUM_BY_MFMA) rs[r] += v;
+                s_a[c][r] = v;
             }
         }
-        if (!SUM_BY_MFMA) l_run[a] = l_run[a] * alpha + (rs2[0] + rs2[1]);
+        if (!SUM_BY_MFMA) l_run[a] = __builtin_fmaf(l_run[a], alpha, (rs[0] + rs[1]) + (rs[2] + rs[3]));
         if (rescale) {
-            const f32x2 al2 = {alpha, alpha};
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                f32x2 lo = {o[a][dt][0], o[a][dt][1]}, hi = {o[a][dt][2], o[a][dt][3]};
-                lo *= al2; hi *= al2;
-                o[a][dt][0] = lo[0]; o[a][dt][1] = lo[1]; o[a][dt][2] = hi[0]; o[a][dt][3] = hi[1];
-            }
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[a][dt][r] *= alpha;
         }
         f16x8 pf[2];
 #pragma unroll

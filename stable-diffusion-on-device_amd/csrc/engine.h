@@ -96,6 +96,19 @@ private:
     float* qoff_ = nullptr;   // order of the weight arena, so that a fused parameter group is one contiguous run
     size_t qrows_ = 0;
     bool quant_mode() const { return cfg_.weight_quant != 0 && (kind_ == SDOD_GRAPH_UNET || kind_ == SDOD_GRAPH_TEMB); }
+    // weight_quant = 1: every conv / Linear weight stays affine uint8 in HBM.  weight_quant = 2 ("where it pays"): the codes are
+    // streamed only by the blocks whose GEMMs have at most kQuantAutoMaxRows rows; every other block's tensors are dequantised
+    // ONCE at load (set_param: the reference's arithmetic, qnn_context.cpp:1018-1033) and the block is built exactly as in an
+    // fp16 graph (LayerNorm fold, fused skip conv, composed ff.net.2 + proj_out).  Measured on MI355X (batch 2, SD v2.1 shapes,
+    // profiles/r03_config5_op_tables.txt): no GEMM of the UNet is weight-BANDWIDTH bound -- the deepest 3x3 convolutions move
+    // 15-30 MB of weights in 14-25 us, 1-1.5 TB/s -- so halving the stream buys nothing while the expansion is VALU work on an
+    // issue-bound loop: uint8 loses 30-50 % on the convolutions with >= 1152 rows, ~1 % over the 288-row level (12x12 at 768 px),
+    // and ties at 72 rows.  Hence 128: at config 5's own size the setting builds the fp16 graph from the uint8 checkpoint.
+    // quant_decl_ is the decision for the block being built: identical in every build pass (it depends on the row count only).
+    static constexpr int kQuantAutoMaxRows = 128;
+    bool quant_decl_ = false;
+    void quant_rows(int rows) { quant_decl_ = quant_mode() && (cfg_.weight_quant == 1 || rows <= kQuantAutoMaxRows); }
+    void quant_global() { quant_decl_ = quant_mode(); }
     const float* qscale_of(int w) const { return params_[w].quant ? qscale_ + params_[w].qrow : nullptr; }
     const float* qoff_of(int w) const { return params_[w].quant ? qoff_ + params_[w].qrow : nullptr; }
     int P(const std::string& name, std::vector<int64_t> shape, ParamKind kind, const std::string& group = "");

@@ -105,7 +105,7 @@ int Graph::P(const std::string& name, std::vector<int64_t> shape, ParamKind kind
     p.name = name;
     p.shape = std::move(shape);
     p.kind = kind;
-    p.quant = quant_mode() && (kind == PK_CONV3 || kind == PK_CONV1 || kind == PK_LINEAR || kind == PK_LINEAR_GEGLU);
+    p.quant = quant_decl_ && (kind == PK_CONV3 || kind == PK_CONV1 || kind == PK_LINEAR || kind == PK_LINEAR_GEGLU);
     p.dev_bytes = param_dev_bytes(p);
     if (!group.empty()) {
         auto it = gindex_.find(group);
@@ -256,7 +256,7 @@ void Graph::set_param(const std::string& name, const void* data, int dtype, cons
     if (p.quant) {
         // the tensor stays affine uint8: repack the CODES exactly as the fp16 path repacks values (KRSC for 3x3 convs, 16-row
         // value / gate interleave for GEGLU) and record its encoding for every output row
-        SDOD_REQUIRE(dtype == SDOD_U8Q, "graph was created with weight_quant = 1: '" + name + "' must be given as SDOD_U8Q");
+        SDOD_REQUIRE(dtype == SDOD_U8Q, "graph was created with weight_quant != 0: '" + name + "' must be given as SDOD_U8Q");
         bool same = (int)p.shape.size() == ndim;
         for (int i = 0; same && i < ndim; ++i) same = p.shape[i] == shape[i];
         if (!same && want == got && (p.kind == PK_CONV1 || p.kind == PK_LINEAR) && ndim >= 2 && shape[0] == p.shape[0]) same = true;
@@ -937,6 +937,7 @@ void Graph::attention(const f16* q, const f16* k, const f16* v, f16* out, int B,
 
 // ------------------------------------------------------------------------------------------ finalize / run
 void Graph::build() {
+    quant_global(); // (the UNet builder narrows it block by block: quant_rows())
     switch (kind_) {
     case SDOD_GRAPH_UNET: build_unet(); break;
     case SDOD_GRAPH_VAE_DECODER: build_vae(); break;

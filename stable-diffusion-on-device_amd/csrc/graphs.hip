@@ -36,13 +36,14 @@ const char* Graph::group_base(const std::string& group) const {
 // ------------------------------------------------------------------------------------------------ UNet
 Act Graph::res_block(const std::string& pfx, const Act& x, const Act* x2, int cout, const f16* emb_all, int emb_ld, int& emb_off) {
     const int cin = x.c + (x2 ? x2->c : 0);
+    quant_rows(x.rows());
     const int n1w = P(pfx + ".in_layers.0.weight", {cin}, PK_VEC), n1b = P(pfx + ".in_layers.0.bias", {cin}, PK_VEC);
     const int c1w = P(pfx + ".in_layers.2.weight", {cout, cin, 3, 3}, PK_CONV3), c1b = P(pfx + ".in_layers.2.bias", {cout}, PK_VEC);
     const int n2w = P(pfx + ".out_layers.0.weight", {cout}, PK_VEC), n2b = P(pfx + ".out_layers.0.bias", {cout}, PK_VEC);
     // out_layers.3 (3x3) and skip_connection (1x1) share ONE weight matrix [cout][9*cout + cin]: the skip conv is the tail
     // K-segment of the same GEMM (one launch, no intermediate skip tensor)
     int c2w, skw = -1, skb = -1;
-    const bool fuse_skip = !quant_mode(); // uint8 weights: the skip conv's tensor has its own encoding -> its own GEMM
+    const bool fuse_skip = !quant_decl_; // uint8 weights: the skip conv's tensor has its own encoding -> its own GEMM
     if (cin != cout && !fuse_skip) {
         c2w = P(pfx + ".out_layers.3.weight", {cout, cout, 3, 3}, PK_CONV3);
         skw = P(pfx + ".skip_connection.weight", {cout, cin, 1, 1}, PK_CONV1);
@@ -98,6 +99,8 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     const int d = C / heads;
     const int rows = x.rows(), L = x.h * x.w, B = x.n;
     const std::string tb = pfx + ".transformer_blocks.0";
+    quant_rows(rows);
+    const bool quant_block = quant_decl_;
     const int nw = P(pfx + ".norm.weight", {C}, PK_VEC), nb = P(pfx + ".norm.bias", {C}, PK_VEC);
     const bool lin = cfg_.linear_proj != 0; // SD2.x stores these as Linear [C, C]; the arithmetic is the same
     const int piw = lin ? P(pfx + ".proj_in.weight", {C, C}, PK_LINEAR) : P(pfx + ".proj_in.weight", {C, C, 1, 1}, PK_CONV1);
@@ -112,8 +115,10 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     const int q2w = P(tb + ".attn2.to_q.weight", {C, C}, PK_LINEAR);
     // every layer's to_k|to_v lives in ONE group: the context projections of all 16 transformers are a single GEMM that
     // runs once per prompt (the context is constant over the sampler run), see build_unet()
+    quant_global(); // (one encoding policy for the whole group: its GEMM runs on M = 77 rows per prompt)
     P(tb + ".attn2.to_k.weight", {C, cd}, PK_LINEAR, "attn2_kv_all");
     P(tb + ".attn2.to_v.weight", {C, cd}, PK_LINEAR, "attn2_kv_all");
+    quant_decl_ = quant_block;
     const int my_kv = kv_off_;
     kv_off_ += 2 * C;
     const int o2w = P(tb + ".attn2.to_out.0.weight", {C, C}, PK_LINEAR), o2b = P(tb + ".attn2.to_out.0.bias", {C}, PK_VEC);
@@ -127,7 +132,7 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     // concatenated buffer.  One launch and one [rows][C] round trip less per transformer block.  Not with uint8 weights (integer
     // codes cannot be composed); SDOD_COMPOSE=0 keeps the two-GEMM form (A/B switch).
     static const bool compose_on = [] { const char* e = std::getenv("SDOD_COMPOSE"); return !(e && e[0] == '0'); }();
-    const bool compose = compose_on && !quant_mode();
+    const bool compose = compose_on && !quant_block;
     int f2w, pow_;
     if (compose) {
         f2w = Pc(tb + ".ff.net.2.weight", {C, 4 * C}, PK_LINEAR, 5 * C, 0, -1);
@@ -148,7 +153,7 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     // self-attention
     // the three LayerNorms of the block are folded into the Linear that consumes them (no LN launch, no LN tensor) -- except
     // with uint8 weights, whose integer codes cannot absorb gamma: there LayerNorm is a launch and the Linear a plain one
-    const bool fold = !quant_mode();
+    const bool fold = !quant_block;
     auto normed = [&](const Act& src, int lw, int lb) -> Act { return layer_norm(src, lw, lb, 1e-5f); };
     f16* qkv = alloc((size_t)rows * 3 * C);
     if (fold) {
@@ -283,6 +288,7 @@ void Graph::build_unet() {
         }
         if (level != 3) {
             const std::string pfx = "input_blocks." + std::to_string(idx++) + ".0.op";
+            quant_rows(h.rows() / 4);
             const int w = P(pfx + ".weight", {ch, ch, 3, 3}, PK_CONV3), b = P(pfx + ".bias", {ch}, PK_VEC);
             GemmOpt o; o.bias = b;
             h = conv(h, nullptr, w, ch, 3, 2, false, o);
@@ -316,6 +322,7 @@ void Graph::build_unet() {
             }
             if (level != 0 && i == 2) {
                 const std::string up = pfx + "." + std::to_string(sub) + ".conv";
+                quant_rows(r.rows() * 4);
                 const int w = P(up + ".weight", {ch, ch, 3, 3}, PK_CONV3), b = P(up + ".bias", {ch}, PK_VEC);
                 GemmOpt o; o.bias = b;
                 Act u = conv(r, nullptr, w, ch, 3, 1, true, o);
@@ -327,6 +334,7 @@ void Graph::build_unet() {
         }
     }
     const int ow = P("out.0.weight", {ch}, PK_VEC), ob = P("out.0.bias", {ch}, PK_VEC);
+    quant_rows(h.rows());
     const int cw = P("out.2.weight", {LC, ch, 3, 3}, PK_CONV3), cb = P("out.2.bias", {LC}, PK_VEC);
     Act g = group_norm(h, nullptr, ow, ob, 1e-5f, true);
     release(h);

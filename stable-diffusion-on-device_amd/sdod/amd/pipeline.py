@@ -32,7 +32,8 @@ class Txt2Img:
         # round-1 behaviour (dequantise once at load, fp16 in HBM)
         if weight_quant is None:
             weight_quant = state_dicts is not None and any(hasattr(v, 'payload') and len(v.shape) >= 2 for v in state_dicts['unet'].values())
-        self.cfg.weight_quant = 1 if weight_quant else 0
+        # weight_quant='auto' (or 2): stream the codes only where that is not slower than fp16 (sdod_model_config.weight_quant = 2)
+        self.cfg.weight_quant = 2 if weight_quant in ('auto', 2) else 1 if weight_quant else 0
         # latency mode: the two halves of the classifier-free-guidance batch run on TWO GPUs -- even rank =
         # unconditional, odd rank = conditional -- and exchange their [n,H,W,4] fp16 predictions once per UNet evaluation
         # (32 KB per image over xGMI); everything after the exchange is computed redundantly, so both ranks hold the image

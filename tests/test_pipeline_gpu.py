@@ -218,6 +218,42 @@ def test_config5_unet_step_at_768px_uint8_weights_in_hbm(rig21):
     print('config 5 UNet step @96x96, uint8 weights: %.2f ms per replay' % (ev0.elapsed_time(ev1) / 5))
 
 
+def test_config5_unet_step_weight_quant_where_it_pays(rig21):
+    """weight_quant = 2 (sdod_engine.h): the same uint8 checkpoint, but only the blocks whose GEMMs have <= 128 rows keep their
+    codes in HBM and stream them; every other block is dequantised once at load and built as in an fp16 graph (LayerNorm fold,
+    fused skip conv, composed ff.net.2 + proj_out).  At 24x24 latents, batch 2, that is the 6x6 / 3x3 levels (72 / 18 rows)
+    against the 24x24 / 12x12 levels (1152 / 288 rows): both kinds of block in one graph.  Same oracle and tolerance as the
+    other two settings; the weight arena sits between theirs; the launch list is shorter than with every tensor uint8."""
+    from sdod.amd import engine as E
+    sds, unet = rig21
+    gen = torch.Generator().manual_seed(79)
+    x = torch.randn(2, 4, 24, 24, generator=gen)
+    ctx = torch.randn(2, 77, 1024, generator=gen).half()
+    with torch.no_grad():
+        ref = unet(x, torch.tensor([601.0, 601.0]), ctx.float())
+    outs, stats, launches = {}, {}, {}
+    for wq in (0, 1, 2):
+        cfg = E.sd21_config(24, 24)
+        cfg.weight_quant = wq
+        g = E.UNet(cfg, 2)
+        g.load_state_dict(sds['unet'])
+        g.finalize()
+        te = E.Temb(cfg, 1)
+        te.load_state_dict(sds['temb'])
+        te.finalize()
+        te.t.copy_(torch.tensor([601.0]))
+        te.execute()
+        g.x.copy_(x); g.ctx.copy_(ctx); g.temb.copy_(te.out.expand(2, -1))
+        g.execute(True)
+        outs[wq] = g.eps.float().cpu().permute(0, 3, 1, 2)
+        stats[wq], launches[wq] = g.stats(), len(g.op_table())
+        r = rel_l2(outs[wq], ref)
+        print(f'config 5 UNet step @24x24, weight_quant = {wq}: rel-L2 {r:.3e}, {stats[wq]["weight_bytes"] / 1e9:.3f} GB of weights, {launches[wq]} launches')
+        assert torch.isfinite(outs[wq]).all() and r <= 1e-2, (wq, r)
+    assert stats[1]['weight_bytes'] < stats[2]['weight_bytes'] < stats[0]['weight_bytes']
+    assert launches[0] <= launches[2] < launches[1]
+
+
 def test_config5_unet_step_at_768px(rig21):
     """one batch-2 UNet evaluation at the full 96x96 latent of SD v2.1-768 (L = 9216 tokens at 64-wide heads)"""
     from sdod.amd import engine as E

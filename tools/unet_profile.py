@@ -16,10 +16,12 @@ ap.add_argument('--batch', type=int, default=2)
 ap.add_argument('--top', type=int, default=70)
 ap.add_argument('--model', default='sd14', choices=['sd14', 'sd21'], help='sd21: SD v2.1-768 UNet shapes (config 5), use --hw 96')
 ap.add_argument('--quant', action='store_true', help='keep the conv / linear weights affine uint8 in HBM (config 5: sdod_model_config.weight_quant)')
+ap.add_argument('--quant-auto', action='store_true', help='weight_quant = 2: uint8 codes streamed only by the blocks with <= 128 rows, the rest dequantised at load')
 a = ap.parse_args()
+a.quant = a.quant or a.quant_auto
 cfg = (E.sd21_config if a.model == 'sd21' else E.sd14_config)(a.hw, a.hw)
 if a.quant:
-    cfg.weight_quant = 1
+    cfg.weight_quant = 2 if a.quant_auto else 1
 g = {'unet': E.UNet, 'vae': E.VaeDecoder, 'text': E.TextEncoder}[a.kind](cfg, a.batch if a.kind != 'vae' else 1)
 sd = Wt.synthetic_state_dict(g.param_table(), seed=1, dtype=torch.float32 if a.quant else torch.float16)
 g.load_state_dict(Wt.quantize_state_dict(sd) if a.quant else sd)
