@@ -110,6 +110,16 @@ typedef struct sdod_gemm_desc {
      * eight L2s fetch between them, panels * A + (8 / panels) * W); 1 / 2 / 4 / 8 force it (1 = m-major: every XCD reads all
      * of W; 8 = n-major: every XCD reads all of A).  Speed only. */
     int xcd_panels;
+    /* --- per-image weights (rows mode, LDS-DMA ring tiles): the rows of image i = m / rows_per_img multiply the matrix at
+     * w + i * w_img_stride (elements, a multiple of 8) and take bias / ln_s from + i * vec_img_stride floats (0: shared vectors).
+     * rows_per_img must be a multiple of 32 dividing M; the plan only uses tiles whose rows divide rows_per_img.
+     * softmax_cols = 80: the epilogue replaces every run of 80 output columns by its row softmax in the exp2 domain
+     * (p = 2^(x - max) / sum; N a multiple of 160; columns to be ignored carry a bias of -30000).  Together they are the two
+     * GEMMs of the FOLDED cross-attention (sdod_xattn_fold_f16): scores = LN(x) . (Wq^T K_h^T) with the softmax in the
+     * epilogue, then out = P . (V_h Wo_h^T) + bias + residual. */
+    int w_img_stride;
+    int vec_img_stride;
+    int softmax_cols;
 } sdod_gemm_desc;
 
 SDOD_API int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream);
@@ -226,6 +236,18 @@ SDOD_API int sdod_layer_norm_f16(const void* x, void* y, const float* weight, co
 SDOD_API int sdod_attention_f16(const void* q, const void* k, const void* v, void* out, int batch, int heads,
                                 int lq, int lk, int d, int ldq, int ldk, int ldv, int ldo, float scale, int causal,
                                 void* stream);
+
+/* Folded cross-attention, the once-per-prompt part.  The text context is constant over the sampler run, so to_q and to_out can
+ * be multiplied into K and V: scores_h = LN(x) . W1_h with W1_h = Wq_h^T K_h^T, out = [P_1 | .. | P_H] . [W2_1 ; .. ; W2_H] with
+ * W2_h = V_h Wo_h^T -- two GEMMs per evaluation (sdod_gemm_desc: w_img_stride / vec_img_stride / softmax_cols) instead of
+ * Linear + attention + Linear (the reference's /attn2/to_q, /attn2/MatMul, /attn2/to_out.0 ops, analyze_results.py:69-79).
+ * kv: fp16 [n_img * L][ld_kv], K at column k_off, V at v_off (heads * d columns each), L <= 80 keys; wq: [C][ldq] with the
+ * LayerNorm weight folded in, sq / tq its fold vectors (sdod_ln_fold_f16); wo: [C][ldwo]; scale = the softmax scale.
+ * Writes w1 fp16 [n_img][heads*80][C] (scaled by scale * log2 e), s1 / t1 fp32 [n_img][heads*80] (padding columns: s = 0,
+ * t = -30000), w2 fp16 [n_img][C][heads*80] (padding columns zero). */
+SDOD_API int sdod_xattn_fold_f16(const void* kv, int ld_kv, int k_off, int v_off, int n_img, int L, const void* wq, int ldq,
+                                 const void* sq, const void* tq, const void* wo, int ldwo, int heads, int d, float scale, void* w1,
+                                 void* s1, void* t1, void* w2, void* stream);
 
 /* Row softmax on fp16 [M][N] in place semantics allowed (y may equal x); fp32 math. */
 SDOD_API int sdod_softmax_rows_f16(const void* x, void* y, int m, int n, void* stream);

@@ -414,6 +414,89 @@ hipError_t attn_dispatch(const AttnP& p, bool big, bool tr, hipStream_t st) {
     return big ? attn_launch<D, 2, false>(p, st) : attn_launch<D, 1, false>(p, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Folded cross-attention (once per prompt).  The text context -- and with it every cross-attention K and V -- is constant
+// over the sampler run, so the two Linears around the attention can be multiplied INTO K and V:
+//   scores_h = LN(x) Wq_h^T K_h^T = LN(x) . W1_h,      W1_h = Wq_h^T K_h^T   [C x L]
+//   out      = sum_h P_h V_h Wo_h^T = [P_1 | ... | P_H] . [W2_1 ; ... ; W2_H],   W2_h = V_h Wo_h^T   [L x C]
+// i.e. per evaluation the block is TWO plain GEMMs (the softmax runs in the epilogue of the first, sdod_gemm_desc::softmax_cols)
+// instead of Linear + attention kernel + Linear; L = 77 keys are padded to 80 columns per head.  This kernel builds the
+// per-image matrices: C[bt][m][n] = alpha * sum_k A[bt][m][k] B[bt][n][k] for many small (64 x 64 x d) problems with arbitrary
+// element strides (the operands are slices of the K|V projection and of the weight matrices), rows / columns past the valid
+// range produce zeros.  fp16 in, fp32 accumulate, fp16 out; 16 outputs per thread from LDS tiles.
+struct FoldP {
+    const f16* a; const f16* b; f16* c;
+    long long a_bt0, a_bt1, b_bt0, b_bt1, c_bt0, c_bt1; // batch = (image, head): operand offsets per image / per head (elements)
+    int a_sm, a_sk, b_sn, b_sk, c_sm;                   // element strides (c: stride_n = 1)
+    int M, N, K, m_valid, n_valid, heads;
+    float alpha;
+};
+constexpr int kFoldKMax = 160;
+__global__ __launch_bounds__(256) void xattn_fold_kernel(const FoldP p) {
+    __shared__ f16 sa[kFoldKMax][64 + 8], sb[kFoldKMax][64 + 8];
+    const int tid = threadIdx.x;
+    const int bt = blockIdx.z, img = bt / p.heads, h = bt - img * p.heads;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const f16* a = p.a + img * p.a_bt0 + h * p.a_bt1;
+    const f16* b = p.b + img * p.b_bt0 + h * p.b_bt1;
+    for (int idx = tid; idx < 64 * p.K; idx += 256) {
+        // the faster-running index follows the operand's unit stride, so that neighbouring threads read neighbouring halves
+        int ra, ka, rb, kb;
+        if (p.a_sk == 1) { ra = idx / p.K; ka = idx - ra * p.K; } else { ka = idx >> 6; ra = idx & 63; }
+        if (p.b_sk == 1) { rb = idx / p.K; kb = idx - rb * p.K; } else { kb = idx >> 6; rb = idx & 63; }
+        const int m = m0 + ra, n = n0 + rb;
+        sa[ka][ra] = m < p.m_valid ? a[(long long)m * p.a_sm + (long long)ka * p.a_sk] : (f16)0.f;
+        sb[kb][rb] = n < p.n_valid ? b[(long long)n * p.b_sn + (long long)kb * p.b_sk] : (f16)0.f;
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    float acc[4][4] = {};
+    for (int k = 0; k < p.K; ++k) {
+        const f16x4 av = *reinterpret_cast<const f16x4*>(&sa[k][ty * 4]);
+        const f16x4 bv = *reinterpret_cast<const f16x4*>(&sb[k][tx * 4]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = fmaf((float)av[i], (float)bv[j], acc[i][j]);
+    }
+    f16* c = p.c + img * p.c_bt0 + h * p.c_bt1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i, n = n0 + tx * 4;
+        if (m < p.M && n + 3 < p.N) {
+            f16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (f16)(p.alpha * acc[i][j]);
+            *reinterpret_cast<f16x4*>(c + (long long)m * p.c_sm + n) = o;
+        } else if (m < p.M) {
+            for (int j = 0; j < 4; ++j)
+                if (n + j < p.N) c[(long long)m * p.c_sm + n + j] = (f16)(p.alpha * acc[i][j]);
+        }
+    }
+}
+// the LayerNorm-fold vectors of the score GEMM: s1 = alpha * K_h . s_q, t1 = alpha * K_h . t_q (s_q / t_q: those of the folded
+// to_q Linear); padding columns get s = 0 and a bias that the softmax turns into an exact zero
+__global__ __launch_bounds__(256) void xattn_fold_vec_kernel(const f16* kv, int ld_kv, int k_off, int L, const float* sq, const float* tq,
+                                                             int heads, int d, float alpha, float* s1, float* t1, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx % 80, bh = idx / 80, h = bh % heads, img = bh / heads;
+    if (j >= L) {
+        s1[idx] = 0.f;
+        t1[idx] = -30000.f;
+        return;
+    }
+    const f16* kr = kv + ((long long)img * L + j) * ld_kv + k_off + h * d;
+    float a = 0.f, b = 0.f;
+    for (int dd = 0; dd < d; ++dd) {
+        const float kval = (float)kr[dd];
+        a = fmaf(kval, sq[h * d + dd], a);
+        b = fmaf(kval, tq[h * d + dd], b);
+    }
+    s1[idx] = alpha * a;
+    t1[idx] = alpha * b;
+}
+
 } // namespace
 
 extern "C" int sdod_attention_f16(const void* q, const void* k, const void* v, void* out, int batch, int heads, int lq,
@@ -445,6 +528,38 @@ extern "C" int sdod_attention_f16(const void* q, const void* k, const void* v, v
     default: e = attn_dispatch<160>(p, false, tr, st); break;
     }
     SDOD_HIP_CHECK(e);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_xattn_fold_f16(const void* kv, int ld_kv, int k_off, int v_off, int n_img, int L, const void* wq, int ldq,
+                                   const void* sq, const void* tq, const void* wo, int ldwo, int heads, int d, float scale, void* w1,
+                                   void* s1, void* t1, void* w2, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(kv && wq && sq && tq && wo && w1 && s1 && t1 && w2, "null pointer");
+    SDOD_REQUIRE(n_img > 0 && heads > 0 && d > 0 && d <= kFoldKMax && d % 4 == 0 && L > 0 && L <= 80, "bad shape (d <= 160, L <= 80)");
+    const int C = heads * d, NK = heads * 80;
+    SDOD_REQUIRE(C % 4 == 0 && ldq >= C && ldwo >= C && ld_kv >= C, "bad strides");
+    hipStream_t st = (hipStream_t)stream;
+    const float alpha = scale * 1.4426950408889634f; // the softmax of the score GEMM's epilogue works in the exp2 domain
+    // W1[img][(h, j)][c] = alpha * sum_dd K[img, j, (h, dd)] * Wq'[(h, dd)][c]
+    FoldP p{};
+    p.a = (const f16*)kv + k_off; p.a_bt0 = (long long)L * ld_kv; p.a_bt1 = d; p.a_sm = ld_kv; p.a_sk = 1;
+    p.b = (const f16*)wq; p.b_bt0 = 0; p.b_bt1 = (long long)d * ldq; p.b_sn = 1; p.b_sk = ldq;
+    p.c = (f16*)w1; p.c_bt0 = (long long)NK * C; p.c_bt1 = (long long)80 * C; p.c_sm = C;
+    p.M = 80; p.N = C; p.K = d; p.m_valid = L; p.n_valid = C; p.heads = heads; p.alpha = alpha;
+    SDOD_LAUNCH(xattn_fold_kernel, dim3((C + 63) / 64, 2, n_img * heads), dim3(256), 0, st, p);
+    const int total = n_img * NK;
+    SDOD_LAUNCH(xattn_fold_vec_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const f16*)kv, ld_kv, k_off, L, (const float*)sq,
+                (const float*)tq, heads, d, alpha, (float*)s1, (float*)t1, total);
+    // W2[img][c][(h, j)] = sum_dd Wo[c][(h, dd)] * V[img, j, (h, dd)]
+    FoldP q{};
+    q.a = (const f16*)wo; q.a_bt0 = 0; q.a_bt1 = d; q.a_sm = ldwo; q.a_sk = 1;
+    q.b = (const f16*)kv + v_off; q.b_bt0 = (long long)L * ld_kv; q.b_bt1 = d; q.b_sn = ld_kv; q.b_sk = 1;
+    q.c = (f16*)w2; q.c_bt0 = (long long)C * NK; q.c_bt1 = 80; q.c_sm = NK;
+    q.M = C; q.N = 80; q.K = d; q.m_valid = C; q.n_valid = L; q.heads = heads; q.alpha = 1.0f;
+    SDOD_LAUNCH(xattn_fold_kernel, dim3(2, (C + 63) / 64, n_img * heads), dim3(256), 0, st, q);
+    SDOD_HIP_CHECK(hipGetLastError());
     return 0;
     SDOD_CATCH
 }

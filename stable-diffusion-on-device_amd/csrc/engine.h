@@ -189,7 +189,14 @@ private:
         int ln_w = -1, ln_b = -1;  // fold LayerNorm(ln_w, ln_b) of the input rows into this Linear (see sdod_ln_fold_f16)
         const float* wq_scale = nullptr; // uint8 weights (linear_raw on a fused group): per-row scale / offset + 128 vectors
         const float* wq_off = nullptr;
+        const float* ln_s_raw = nullptr; // LayerNorm fold with vectors the caller owns: ln_s (bias_raw carries the matching t)
+        int w_img_stride = 0, vec_img_stride = 0; // per-image weights / vectors (sdod_gemm_desc), with rows_per_img
+        int softmax_cols = 0;
     };
+    // registers the LayerNorm fold of Linear `w_param` ([N][K], row stride ldw): gamma is multiplied into W in place at finalize,
+    // the returned device vectors (owned by the graph) are s[n] = sum_k W'[n][k] and t[n] = sum_k beta[k] W[n][k] + bias[n]
+    struct LnVecs { float* s; float* t; };
+    LnVecs ln_fold_vectors(f16* w, int N, int K, int ldw, int ln_w, int ln_b, const float* bias);
     struct FoldJob {
         f16* w; int n, k, ldw;
         const float *gamma, *beta, *bias_in;

@@ -491,7 +491,8 @@ const int kCandidates[] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 17, 18, 1
                            37, 38, 39, 40, 41, 42, 43, 44, 45, // halo-patch convolution tiles: rejected by every other descriptor
                            46, 47, 48,
                            49, 50, 51, 52, // halo-patch tiles of 96 / 192 rows (image rows that are multiples of 3: config 5)
-                           53, 54, 55};    // A-panel tiles (short-K wide-N Linears): rejected by every other descriptor
+                           53, 54, 55,     // A-panel tiles (short-K wide-N Linears): rejected by every other descriptor
+                           56, 57, 58};    // 160-wide ring tiles for the softmax-epilogue GEMM of the folded cross-attention
 
 struct ShapeKey {
     static constexpr int kFields = 14;
@@ -607,7 +608,7 @@ ShapeKey key_of(const sdod_gemm_desc& d) {
     // w_in and n_img are part of the key: which halo-patch tiles take a convolution depends on both (halo_geometry), so two
     // convolutions with equal M and h_in but different (n_img, w_in) must not share a pick
     return ShapeKey{{d.a_mode, d.M, d.N, d.K, d.c0, d.c1, d.stride, d.upsample, d.ksize, d.h_in,
-                     (d.residual ? 1 : 0) + (d.geglu ? 2 : 0) + 4 * d.tc0 + 16384 * d.tc1 + (d.ln ? (1 << 30) : 0) + (d.wq ? (1 << 29) : 0), d.lda,
+                     (d.residual ? 1 : 0) + (d.geglu ? 2 : 0) + 4 * d.tc0 + 16384 * d.tc1 + (d.ln ? (1 << 30) : 0) + (d.wq ? (1 << 29) : 0) + (d.softmax_cols ? (1 << 28) : 0) + (d.w_img_stride ? (1 << 27) : 0), d.lda,
                      d.a_mode == SDOD_A_CONV3X3 ? d.w_in : 0, d.a_mode == SDOD_A_CONV3X3 ? d.n_img : 0}};
 }
 // a table pick the library would refuse at launch (a halo-patch / A-panel tile that does not take this descriptor: a stale or
@@ -677,6 +678,7 @@ void Graph::emit_gemm(sdod_gemm_desc d) {
                 h.split_k = 0;
                 int tt = 0, sp = 1;
                 (void)sdod_gemm_plan(&h, &tt, &sp);
+                if (tt != t) continue; // the plan runs this descriptor on another tile (a fusion `t` does not carry): that tile is a candidate itself
                 int tried[4] = {sp, 1, sp / 2, sp > 1 ? sp * 2 : 0};
                 for (int k = 0; k < 4; ++k) {
                     const int want = tried[k];
@@ -806,21 +808,31 @@ void Graph::linear_raw(const f16* x, int rows, int K, const f16* w, int ldw, int
         d.ln = 1;
         d.ln_eps = 1e-5f;
         if (mode_ == REAL) {
-            float *sv = nullptr, *tv = nullptr;
-            SDOD_HIP_CHECK(hipMalloc((void**)&sv, (size_t)N * sizeof(float)));
-            SDOD_HIP_CHECK(hipMalloc((void**)&tv, (size_t)N * sizeof(float)));
-            derived_.push_back(sv);
-            derived_.push_back(tv);
-            fold_jobs_.push_back(FoldJob{const_cast<f16*>(w), N, K, ldw, W<float>(o.ln_w), W<float>(o.ln_b),
-                                         reinterpret_cast<const float*>(d.bias), sv, tv});
-            d.ln_s = sv;
-            d.bias = tv;
+            const LnVecs v = ln_fold_vectors(const_cast<f16*>(w), N, K, ldw, o.ln_w, o.ln_b, reinterpret_cast<const float*>(d.bias));
+            d.ln_s = v.s;
+            d.bias = v.t;
         } else {
             d.ln_s = d.w; // placeholder pointers for the sizing pass
             d.bias = d.w;
         }
     }
+    if (o.ln_s_raw) {
+        d.ln = 1;
+        d.ln_eps = 1e-5f;
+        d.ln_s = o.ln_s_raw;
+    }
+    d.w_img_stride = o.w_img_stride; d.vec_img_stride = o.vec_img_stride; d.softmax_cols = o.softmax_cols;
     emit_gemm(d);
+}
+
+Graph::LnVecs Graph::ln_fold_vectors(f16* w, int N, int K, int ldw, int ln_w, int ln_b, const float* bias) {
+    float *sv = nullptr, *tv = nullptr;
+    SDOD_HIP_CHECK(hipMalloc((void**)&sv, (size_t)N * sizeof(float)));
+    SDOD_HIP_CHECK(hipMalloc((void**)&tv, (size_t)N * sizeof(float)));
+    derived_.push_back(sv);
+    derived_.push_back(tv);
+    fold_jobs_.push_back(FoldJob{w, N, K, ldw, W<float>(ln_w), W<float>(ln_b), bias, sv, tv});
+    return LnVecs{sv, tv};
 }
 
 void Graph::linear(const f16* x, int rows, int K, int w, int N, f16* out, const GemmOpt& o) {

@@ -70,6 +70,11 @@ struct GemmP {
     const float* w_off;
     int fixup;               // split-K without a reduce launch: the last slice to arrive at a tile's counter reduces (conv_halo_kernel)
     unsigned* fix_counters;  // [tiles_m * tiles_n], zero when idle (in the caller's zeroed workspace, behind the partial slabs)
+    // per-image weights (rows mode, gemm_glds_kernel): the rows of image i = m / rows_per_img multiply w + i * w_img_stride (halves) and
+    // take their per-column vectors (bias, ln_s) from + i * vec_img_stride (floats); tiles never straddle images (BM | rows_per_img)
+    int w_img_stride, vec_img_stride;
+    unsigned mg_rpi, sh_rpi; // m / rows_per_img
+    int softmax_g;           // 80: the epilogue replaces every run of 80 columns (one wave's columns) by its row softmax, exp2 domain
     int no_respf; // developer switch (SDOD_GEMM_RESPF=0): no early residual prefetch
     int lean; // plain row-major operands whose byte offsets fit 32 bits: the loaders take the short issue path
     // halo-patch convolution (conv_halo_kernel, tiles 37..): geometry of one workgroup's output tile and of the input patch
@@ -562,6 +567,16 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
     tile_of(p, lid, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int split = blockIdx.z;
+    // per-image operands (the folded cross-attention GEMMs: one weight matrix per prompt of the batch)
+    const f16* w_img = p.w;
+    const float* bias_img = p.bias;
+    const float* lns_img = p.ln_s;
+    if (p.w_img_stride != 0) {
+        const int img = fast_div(m0, p.mg_rpi, p.sh_rpi);
+        w_img += (size_t)img * p.w_img_stride;
+        if (bias_img != nullptr) bias_img += (size_t)img * p.vec_img_stride;
+        if (lns_img != nullptr) lns_img += (size_t)img * p.vec_img_stride;
+    }
 
     const int KT = p.K / BK;
     int kt_begin = 0, kt_end = KT;
@@ -615,7 +630,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
         for (int i = 0; i < B_LD; ++i) {
             if (!WQ) {
                 const int n = n0 + (i * NL + lw) * 8 + lrow;
-                b_row[i] = n < p.N ? p.w + (size_t)n * p.ldw + lchunk * 8 : zeros;
+                b_row[i] = n < p.N ? w_img + (size_t)n * p.ldw + lchunk * 8 : zeros;
             } else {
                 // uint8 weights: a slab row is 64 bytes = 4 chunks of 16; lanes 0..31 of a DMA instruction cover the same 8 rows
                 // (lanes 32..63 idle, so the instruction count -- and the vmcnt arithmetic -- equals the fp16 form); chunks
@@ -623,7 +638,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                 const int r = (i * NL + lw) * 8 + ((lane & 31) >> 2);
                 const int n = n0 + r;
                 const int lc = (lane & 3) ^ ((r >> 2) & 3);
-                b_row[i] = n < p.N ? reinterpret_cast<const f16*>(reinterpret_cast<const unsigned char*>(p.w) + (size_t)n * p.ldw + lc * 16) : zeros;
+                b_row[i] = n < p.N ? reinterpret_cast<const f16*>(reinterpret_cast<const unsigned char*>(w_img) + (size_t)n * p.ldw + lc * 16) : zeros;
             }
         }
     };
@@ -662,7 +677,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
         f16* sB = sA + BM * 64;
         if (lean) {
             const f16* ab = p.a0 + k0;
-            const f16* wb = WQ ? reinterpret_cast<const f16*>(reinterpret_cast<const unsigned char*>(p.w) + k0) : p.w + k0;
+            const f16* wb = WQ ? reinterpret_cast<const f16*>(reinterpret_cast<const unsigned char*>(w_img) + k0) : w_img + k0;
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) lds_dma16_saddr(ab, a_off[i], sA + (i * NL + lw) * 8 * 64);
 #pragma unroll
@@ -778,8 +793,8 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
         for (int job = wave; job < 4 * CHUNKS; job += NW) { // wave-uniform
             const int vec = job / CHUNKS, q = job - vec * CHUNKS;
             const int c = q * 64 + lane, n = n0 + c;
-            const float* base = vec == 0 ? ((p.bias != nullptr && !p.bias_on_m) ? p.bias : nullptr) : vec == 1 ? p.bias2
-                              : vec == 2 ? (p.ln ? p.ln_s : nullptr) : (WQ ? p.w_scale : nullptr);
+            const float* base = vec == 0 ? ((bias_img != nullptr && !p.bias_on_m) ? bias_img : nullptr) : vec == 1 ? p.bias2
+                              : vec == 2 ? (p.ln ? lns_img : nullptr) : (WQ ? p.w_scale : nullptr);
             const float* g = (base != nullptr && n < p.N) ? base + n : zf;
             if (c < BN) __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(colv + vec * BN + q * 64), 4, 0, 0);
         }
@@ -870,7 +885,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                 const unsigned smem_base = (unsigned)(uintptr_t)(lds_void_ptr)smem;
                 const unsigned a_dst0 = smem_base + (unsigned)(lw * 8 * 64) * 2u, b_dst0 = a_dst0 + (unsigned)(BM * 64) * 2u;
                 const char* a_ptr = reinterpret_cast<const char*>(p.a0) + (size_t)kt_begin * BK * 2;
-                const char* w_ptr = reinterpret_cast<const char*>(p.w) + (size_t)kt_begin * BK * (WQ ? 1 : 2);
+                const char* w_ptr = reinterpret_cast<const char*>(w_img) + (size_t)kt_begin * BK * (WQ ? 1 : 2);
                 unsigned slot_off = 0;
                 auto issue_lean = [&]() {
 #pragma unroll
@@ -1271,6 +1286,39 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                         for (int j = 0; j < TN; ++j)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) acc[i][j][r] = quick_gelu_f(acc[i][j][r]);
+                }
+            }
+        }
+        if constexpr (WTN == 80 && !WQ) {
+            // Row softmax over the wave's 80 columns (the folded cross-attention: one head's 77 keys + 3 padding columns whose
+            // bias is -30000, scores already in log2 units): a row's columns sit in this lane (TN blocks x 4) and in the three
+            // lanes 16 / 32 / 48 away -- two xor-shuffles per reduction, nothing leaves the wave.
+            if (p.softmax_g) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float mx = acc[i][0][0];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    float sum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = __builtin_amdgcn_exp2f(acc[i][j][r] - mx);
+                            acc[i][j][r] = e;
+                            sum += e;
+                        }
+                    sum += __shfl_xor(sum, 16);
+                    sum += __shfl_xor(sum, 32);
+                    const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] *= inv;
                 }
             }
         }
@@ -2439,8 +2487,15 @@ const TileCfg kTiles[] = {{0, 0},     {128, 128}, {128, 64}, {64, 64},   {256, 1
                           {96, 160}, {96, 64}, {192, 80}, {192, 64},
                           // 53..55: A-panel kernel (gemm_apanel_kernel): row panel x whole K resident in LDS, n-tiles streamed past it --
                           // K = 320 / 640 / 1280 at 128 / 64 / 32 rows (80 KB panels)
-                          {128, 128}, {64, 128}, {32, 128}};
-constexpr int kNumTiles = 55;
+                          {128, 128}, {64, 128}, {32, 128},
+                          // 56..58: 160-wide wave-specialised ring tiles for the score GEMM of the folded cross-attention (the row softmax
+                          // of its epilogue needs a wave that owns a head's 80 columns): a deep ring for the row-starved levels (M = 512 /
+                          // 128: 64 / 16 workgroups, one per CU -- the bytes in flight set the pace), a 128-row tile (M = 8192 x N = 640
+                          // is exactly 256 workgroups) and a two-stage 64-row one that leaves room for two workgroups per CU
+                          {32, 160}, {128, 160}, {64, 160}};
+constexpr int kNumTiles = 58;
+constexpr bool is_ring_tile(int t) { return (t >= 6 && t <= 36) || (t >= 46 && t <= 48) || (t >= 56 && t <= 58); } // gemm_glds_kernel
+constexpr bool is_wave80_tile(int t) { return t == 21 || t == 22 || t == 31 || t == 35 || t == 48 || (t >= 56 && t <= 58); } // 80 columns per wave
 constexpr int kFirstPanelTile = 53, kLastPanelTile = 55;
 constexpr bool is_panel_tile(int t) { return t >= kFirstPanelTile && t <= kLastPanelTile; }
 constexpr int kPanelStages = 4;
@@ -2675,10 +2730,16 @@ Plan make_plan(const sdod_gemm_desc* d) {
     int tile = d->tile;
     const bool fused = d->geglu || d->k_tail || d->ln || d->wq;
     if (fused && (tile < 6 || tile > kNumTiles)) tile = 14; // fusions live in the LDS-DMA kernel family only
-    if (d->geglu && (tile == 21 || tile == 22 || tile == 31 || tile == 35 || tile == 48)) tile = 14;
+    if (d->geglu && is_wave80_tile(tile)) tile = 14;
     if (d->wq && !(tile == 8 || tile == 13 || tile == 23 || tile == 24 || (tile >= 27 && tile <= 31) || is_halo_tile(tile)))
         tile = 23; // uint8-weight variants
     if (d->wq && d->geglu && tile == 31) tile = 23;  // value/gate pairing needs an even number of 16-column blocks per wave
+    // the row softmax of the epilogue lives in one wave: tiles whose waves own 80 columns (the 160-wide ones)
+    if (d->softmax_cols && !is_wave80_tile(tile)) tile = 31;
+    // per-image weights: an LDS-DMA ring tile whose rows divide the image (a tile must not straddle two weight matrices)
+    if (d->w_img_stride && d->rows_per_img > 0 &&
+        (!is_ring_tile(tile) || d->rows_per_img % kTiles[tile].bm != 0))
+        tile = d->softmax_cols ? (d->rows_per_img % 64 == 0 ? 31 : 48) : (d->rows_per_img % 64 == 0 ? 27 : 46);
     if (tile <= 0 || tile > kNumTiles) {
         if (d->N <= 16) {
             tile = 4;
@@ -2692,7 +2753,7 @@ Plan make_plan(const sdod_gemm_desc* d) {
     }
     pl.tile = tile;
     int splits = d->split_k;
-    if (d->geglu || d->ln) splits = 1; // the split-K reducer neither pairs value/gate columns nor sees whole rows
+    if (d->geglu || d->ln || d->softmax_cols || d->vec_img_stride) splits = 1; // the split-K reducer neither pairs value/gate columns nor sees whole rows (nor per-image vectors)
     if (splits <= 0) {
         splits = 1;
         const int nt = ntiles(tile);
@@ -2813,7 +2874,8 @@ extern "C" int sdod_gemm_tile_info(int tile, int out[7]) {
         {32, 64, 2, 2, 6, 1, 1}, {32, 128, 1, 4, 6, 1, 1}, {32, 160, 2, 2, 4, 1, 1},
         {96, 160, 2, 2, 3, 2, 1}, {96, 64, 2, 2, 4, 2, 1}, {192, 80, 4, 1, 4, 2, 1}, {192, 64, 4, 1, 4, 2, 1},
         // SPEC column 3 = gemm_apanel_kernel<BM, BN, WM, WN, STAGES>
-        {128, 128, 2, 2, kPanelStages, 3, 1}, {64, 128, 2, 2, kPanelStages, 3, 1}, {32, 128, 2, 2, kPanelStages, 3, 1}};
+        {128, 128, 2, 2, kPanelStages, 3, 1}, {64, 128, 2, 2, kPanelStages, 3, 1}, {32, 128, 2, 2, kPanelStages, 3, 1},
+        {32, 160, 2, 2, 6, 1, 1}, {128, 160, 2, 2, 3, 1, 1}, {64, 160, 2, 2, 2, 1, 1}};
     static_assert(sizeof(kInfo) / sizeof(kInfo[0]) == kNumTiles + 1, "one row per tile");
     if (tile < 1 || tile > kNumTiles || !out) return sdod::INVALID_ARGUMENT;
     for (int i = 0; i < 7; ++i) out[i] = kInfo[tile][i];
@@ -2923,6 +2985,17 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         p.c0 = d->K; p.c1 = 0; p.h_in = p.w_in = p.h_out = p.w_out = 1; p.stride = 1; p.ksize = 1;
         p.sa0 = d->lda; p.sa1 = 0;
     }
+    p.w_img_stride = d->w_img_stride;
+    p.vec_img_stride = d->vec_img_stride;
+    p.softmax_g = d->softmax_cols;
+    make_magic((unsigned)p.rows_per_img, &p.mg_rpi, &p.sh_rpi);
+    if (d->w_img_stride || d->vec_img_stride)
+        SDOD_REQUIRE(d->w_img_stride > 0 && d->vec_img_stride >= 0 && d->a_mode == SDOD_A_ROWS && d->rows_per_img > 0 && d->rows_per_img % 32 == 0 &&
+                         d->M % d->rows_per_img == 0 && !d->wq && !d->bias_on_m && !d->k_tail && !d->bias2 && d->w_img_stride % 8 == 0,
+                     "per-image weights: rows mode, rows_per_img a multiple of 32 that divides M, fp16 weights, no bias_on_m / bias2 / tail");
+    if (d->softmax_cols)
+        SDOD_REQUIRE(d->softmax_cols == 80 && d->N % 160 == 0 && !d->geglu && !d->wq && !d->residual && !d->row_bias && d->act == 0 && !d->bias_on_m,
+                     "softmax_cols: 80-column groups (N a multiple of 160), no geglu / uint8 weights / residual / row_bias / act");
     p.lean = (d->a_mode == SDOD_A_ROWS && !d->k_tail && (unsigned long long)d->M * d->lda * 2 < (1ull << 32) &&
               (unsigned long long)d->N * d->ldw * 2 < (1ull << 32) && !lean_disabled()) ? 1 : 0;
     {
@@ -2930,7 +3003,8 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
         p.no_respf = respf_off ? 1 : 0;
     }
     const Plan pl = make_plan(d);
-    SDOD_REQUIRE(!(d->geglu && (pl.tile == 21 || pl.tile == 22 || pl.tile == 31 || pl.tile == 35 || pl.tile == 48)), "geglu needs a tile with an even number of 16-column blocks per wave");
+    SDOD_REQUIRE(!(d->geglu && is_wave80_tile(pl.tile)), "geglu needs a tile with an even number of 16-column blocks per wave");
+    SDOD_REQUIRE(!(d->softmax_cols || d->w_img_stride) || is_ring_tile(pl.tile), "softmax_cols / per-image weights need an LDS-DMA ring tile");
     SDOD_REQUIRE(!(d->geglu || d->k_tail || d->bias2 || d->ln || d->wq) || pl.tile >= 6, "geglu / tail segment / bias2 / ln / uint8 weights need an LDS-DMA tile (6..48)");
     p.splits = pl.splits;
     p.kt_per_split = pl.kt_per_split;
@@ -3054,6 +3128,9 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     case 46: e = launch_glds<32, 64, 2, 2, 6, true>(p, grid, st); break;
     case 47: e = launch_glds<32, 128, 1, 4, 6, true>(p, grid, st); break;
     case 48: e = launch_glds<32, 160, 2, 2, 4, true>(p, grid, st); break;
+    case 56: e = launch_glds<32, 160, 2, 2, 6, true>(p, grid, st); break;
+    case 57: e = launch_glds<128, 160, 2, 2, 3, true>(p, grid, st); break;
+    case 58: e = launch_glds<64, 160, 2, 2, 2, true>(p, grid, st); break;
     default: e = launch_glds<128, 128, 2, 2, 2, true, false, 2>(p, grid, st); break;
     }
     SDOD_HIP_CHECK(e);

@@ -171,7 +171,78 @@ Act Graph::spatial_transformer(const std::string& pfx, const Act& x, const Act& 
     Act t1 = act(B, 1, L, C);
     { GemmOpt o; o.bias = o1b; o.residual = t0.p; linear(a1, rows, C, o1w, C, t1.p, o); }
     release(a1); release(t0);
-    // cross-attention on the text context
+    // cross-attention on the text context.  FOLDED form (attention.hip: sdod_xattn_fold_f16): the context, and with it K and V,
+    // is constant over the sampler run, so to_q is multiplied into K and to_out into V once per prompt (static launch list) and
+    // the block is two GEMMs per evaluation -- scores = LN(t1) . (Wq^T K_h^T) with the row softmax over each head's 77 (+3
+    // padding) columns in the epilogue, then [P_1 | .. | P_H] . (V_h Wo_h^T) + bias + residual -- instead of Linear + attention
+    // kernel + Linear: one launch less per block, and at the deep levels half the weight bytes (2 x 640 x C against 2 x C x C).
+    // Needs the LayerNorm fold (fp16 weights), heads * 80 columns tiled by the 160-wide GEMM tiles and the 64-deep K slabs,
+    // image rows a multiple of 32.  SDOD_XATTN_FOLD=0 keeps the three-launch form (A/B switch).
+    static const bool xfold_on = [] { const char* e = std::getenv("SDOD_XATTN_FOLD"); return !(e && e[0] == '0'); }();
+    const int NK = heads * 80;
+    const bool xfold = xfold_on && fold && ctx.w <= 80 && NK % 320 == 0 && L % 32 == 0 && d <= 160 && d % 4 == 0;
+    if (xfold) {
+        f16 *w1 = nullptr, *w2 = nullptr;
+        float *s1 = nullptr, *t1v = nullptr;
+        f16* wq = reinterpret_cast<f16*>(params_[q2w].dev);
+        const f16* wo = reinterpret_cast<const f16*>(params_[o2w].dev);
+        if (mode_ == REAL) {
+            SDOD_HIP_CHECK(hipMalloc((void**)&w1, (size_t)B * NK * C * sizeof(f16)));
+            SDOD_HIP_CHECK(hipMalloc((void**)&w2, (size_t)B * NK * C * sizeof(f16)));
+            SDOD_HIP_CHECK(hipMalloc((void**)&s1, (size_t)B * NK * sizeof(float)));
+            SDOD_HIP_CHECK(hipMalloc((void**)&t1v, (size_t)B * NK * sizeof(float)));
+            derived_.push_back(w1); derived_.push_back(w2); derived_.push_back(s1); derived_.push_back(t1v);
+            const LnVecs qv = ln_fold_vectors(wq, C, C, C, l2w, l2b, nullptr);
+            const f16* kvp = kv_all_;
+            const int ldkv = kv_total_, koff = my_kv, Lk = ctx.w, hh = heads, dd = d;
+            const float scale = 1.0f / sqrtf((float)d);
+            to_static_ = true;
+            sink().push_back(Op{[=](hipStream_t st) {
+                check_rc2(sdod_xattn_fold_f16(kvp, ldkv, koff, koff + C, B, Lk, wq, C, qv.s, qv.t, wo, C, hh, dd, scale, w1, s1, t1v, w2, st));
+            }, "xattn_fold", 4.0 * B * NK * (double)C * d, 4.0 * B * NK * C * 2, "C" + std::to_string(C) + " d" + std::to_string(d)});
+            to_static_ = false;
+        }
+        const f16* w1p = mode_ == REAL ? w1 : wq; // (placeholders during the sizing pass)
+        const f16* w2p = mode_ == REAL ? w2 : wq;
+        f16* pb = alloc((size_t)rows * NK);
+        { GemmOpt o; o.ln_s_raw = mode_ == REAL ? s1 : reinterpret_cast<const float*>(wq); o.bias_raw = mode_ == REAL ? t1v : reinterpret_cast<const float*>(wq);
+          o.w_img_stride = NK * C; o.vec_img_stride = NK; o.softmax_cols = 80; o.rows_per_img = L;
+          linear_raw(t1.p, rows, C, w1p, C, NK, pb, o); }
+        GemmOpt o2;
+        o2.bias = o2b; o2.residual = t1.p; o2.w_img_stride = C * NK; o2.rows_per_img = L;
+        if (compose) {
+            f16* cat = alloc((size_t)rows * 5 * C);
+            f16* t2c = cat + 4 * C;
+            o2.ldr = C; o2.ldo = 5 * C;
+            linear_raw(pb, rows, NK, w2p, NK, C, t2c, o2);
+            release(pb); release(t1);
+            { GemmOpt o; o.bias = f1b; o.geglu = true; o.ln_w = l3w; o.ln_b = l3b; o.lda = 5 * C; o.ldo = 5 * C; linear(t2c, rows, C, f1w, 8 * C, cat, o); }
+            float* bc = nullptr;
+            if (mode_ == REAL) {
+                SDOD_HIP_CHECK(hipMalloc((void**)&bc, (size_t)C * sizeof(float)));
+                derived_.push_back(bc);
+                f16* wc = reinterpret_cast<f16*>(params_[f2w].dev);
+                compose_jobs_.push_back(ComposeJob{wc, wc + 4 * C, 5 * C, C, C, 4 * C, W<float>(f2b), W<float>(pob), bc});
+            }
+            Act out = act(x.n, x.h, x.w, C);
+            { GemmOpt o; o.bias_raw = mode_ == REAL ? bc : reinterpret_cast<const float*>(params_[f2w].dev); o.residual = x.p;
+              linear_raw(cat, rows, 5 * C, reinterpret_cast<const f16*>(params_[f2w].dev), 5 * C, C, out.p, o); }
+            release(cat);
+            return out;
+        }
+        Act t2 = act(B, 1, L, C);
+        linear_raw(pb, rows, NK, w2p, NK, C, t2.p, o2);
+        release(pb); release(t1);
+        f16* gg = alloc((size_t)rows * 4 * C);
+        { GemmOpt o; o.bias = f1b; o.geglu = true; o.ln_w = l3w; o.ln_b = l3b; linear(t2.p, rows, C, f1w, 8 * C, gg, o); }
+        Act t3 = act(B, 1, L, C);
+        { GemmOpt o; o.bias = f2b; o.residual = t2.p; linear(gg, rows, 4 * C, f2w, C, t3.p, o); }
+        release(gg); release(t2);
+        Act out = act(x.n, x.h, x.w, C);
+        { GemmOpt o; o.bias = pob; o.residual = x.p; linear(t3.p, rows, C, pow_, C, out.p, o); }
+        release(t3);
+        return out;
+    }
     f16* q2 = alloc((size_t)rows * C);
     if (fold) {
         GemmOpt o; o.ln_w = l2w; o.ln_b = l2b; linear(t1.p, rows, C, q2w, C, q2, o);

@@ -48,7 +48,7 @@ def workspace(nbytes, device, tag='default'):
 def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=None, alpha=1.0, out=None,
          conv=None, a2=None, bias_on_m=False, split_k=0, tile=0, time_iters=0, geglu=False, tail=None, bias2=None,
          ln_s=None, ln_eps=1e-5, cold_scratch=None, phase=0, return_desc=False, w_scale=None, w_off=None, fixup=False,
-         xcd=0):
+         xcd=0, softmax_cols=0):
     """out = act(alpha * A @ W^T + bias + row_bias) + residual.
 
     a: fp16 [M, K] (rows mode) or NHWC [N, H, W, C0] with conv=dict(stride=1|2, upsample=bool) (3x3 pad 1);
@@ -61,7 +61,16 @@ def gemm(a, w, bias=None, *, residual=None, row_bias=None, rows_per_img=0, act=N
         d.wq = 1; d.w_scale = _p(w_scale); d.w_off = _p(w_off)
     else:
         _req(w, torch.float16, 'w')
-    nout, k = w.shape
+    per_image = w.dim() == 3   # [n_img, Nout, K]: the rows of image i (rows_per_img each) multiply w[i]; bias / ln_s may be [n_img, Nout]
+    nout, k = w.shape[-2:]
+    if per_image:
+        assert conv is None and rows_per_img > 0 and w.is_contiguous()
+        d.w_img_stride = nout * k
+        d.rows_per_img = rows_per_img
+        if (bias is not None and bias.dim() == 2) or (ln_s is not None and ln_s.dim() == 2):
+            assert (bias is None or bias.dim() == 2) and (ln_s is None or ln_s.dim() == 2)
+            d.vec_img_stride = nout
+    d.softmax_cols = softmax_cols
     if conv is None:
         m = a.shape[0]
         assert a.shape[1] == k, (a.shape, w.shape)
@@ -253,6 +262,24 @@ def attention(q, k, v, heads, scale=None, causal=False, out=None):
     check(lib.sdod_attention_f16(_p(q), _p(k), _p(v), _p(out), b, heads, lq, lk, d, q.shape[2], k.shape[2], v.shape[2],
                                  out.shape[2], scale, 1 if causal else 0, _stream()))
     return out
+
+
+def xattn_fold(kv, k_off, v_off, n_img, L, wq, sq, tq, wo, heads, scale=None):
+    """once-per-prompt part of the folded cross-attention (include/sdod_hip.h: sdod_xattn_fold_f16).  kv: fp16 [n_img * L, ld]
+    holding K at column k_off and V at v_off; wq: LayerNorm-folded to_q weight with its fold vectors sq, tq (ln_fold); wo: to_out
+    weight.  Returns (w1 [n_img, heads*80, C], s1, t1 [n_img, heads*80], w2 [n_img, C, heads*80])."""
+    lib = _lib.hip()
+    _req(kv, torch.float16, 'kv'); _req(wq, torch.float16, 'wq'); _req(wo, torch.float16, 'wo')
+    _req(sq, torch.float32, 'sq'); _req(tq, torch.float32, 'tq')
+    c = wq.shape[0]; d = c // heads
+    if scale is None:
+        scale = d ** -0.5
+    w1 = torch.empty(n_img, heads * 80, c, dtype=torch.float16, device=kv.device)
+    w2 = torch.empty(n_img, c, heads * 80, dtype=torch.float16, device=kv.device)
+    s1 = torch.empty(n_img, heads * 80, dtype=torch.float32, device=kv.device); t1 = torch.empty_like(s1)
+    check(lib.sdod_xattn_fold_f16(_p(kv), kv.shape[-1], k_off, v_off, n_img, L, _p(wq), wq.shape[1], _p(sq), _p(tq), _p(wo), wo.shape[1],
+                                  heads, d, scale, _p(w1), _p(s1), _p(t1), _p(w2), _stream()))
+    return w1, s1, t1, w2
 
 
 def attention_strided(q, k, v, out, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo, scale, causal=False):

@@ -1003,3 +1003,43 @@ def test_image_to_u8_vs_oracle(oracle_lib):
     got = ops.image_to_u8(torch.from_numpy(img).to(d), a=0.5, b=0.5, mode=1).cpu().numpy()
     ref = (255.0 * np.clip((f32 + np.float32(1.0)) / np.float32(2.0), 0, 1)).astype(np.uint8)
     assert np.array_equal(got.reshape(-1), ref)
+
+
+@pytest.mark.parametrize('case', ['64x64 C320 d40', '32x32 C640 d80', '16x16 C1280 d160', '8x8 C1280 d160', 'sd21 24x24 C1280 d64'])
+def test_folded_cross_attention_matches_linear_attention_linear(case):
+    """The cross-attention block as two GEMMs (sdod_xattn_fold_f16 once per prompt; per evaluation a LayerNorm-folded score GEMM
+    with per-image weights and the row softmax in its epilogue, then P . (V Wo^T) + bias + residual with per-image weights)
+    against the three-op form it replaces -- LayerNorm -> to_q -> softmax(q k^T / sqrt d) v -> to_out + residual in fp32 torch
+    (the reference's /attn2/* ops, analyze_results.py:69-79).  Tolerance as the attention / Linear kernel tests."""
+    from sdod.amd import ops
+    hw = int(case.split('x')[0].split()[-1]); c = int(case.split('C')[1].split()[0]); d = int(case.split(' d')[1])
+    heads, L, B, cd = c // d, 77, 2, 768
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    rows = hw * hw
+    x = (torch.randn(B * rows, c, generator=g) * 1.5 + 0.3).half().cuda()
+    ctx = torch.randn(B * L, cd, generator=g).half().cuda()
+    wq = (torch.randn(c, c, generator=g) / c ** 0.5).half().cuda(); wo = (torch.randn(c, c, generator=g) / c ** 0.5).half().cuda()
+    wk = (torch.randn(c, cd, generator=g) / cd ** 0.5).half().cuda(); wv = (torch.randn(c, cd, generator=g) / cd ** 0.5).half().cuda()
+    gamma = (1 + 0.2 * torch.randn(c, generator=g)).cuda(); beta = (0.1 * torch.randn(c, generator=g)).cuda()
+    bo = (0.1 * torch.randn(c, generator=g)).cuda()
+    # reference, fp32, on the same fp16 parameters
+    xf = x.float()
+    ln = torch.nn.functional.layer_norm(xf, (c,), gamma, beta, 1e-5)
+    q = (ln @ wq.float().t()).view(B, rows, heads, d).transpose(1, 2)
+    k = (ctx.float() @ wk.float().t()).view(B, L, heads, d).transpose(1, 2)
+    v = (ctx.float() @ wv.float().t()).view(B, L, heads, d).transpose(1, 2)
+    att = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1) @ v
+    ref = att.transpose(1, 2).reshape(B * rows, c) @ wo.float().t() + bo + xf
+    # the folded form: K | V projection (one GEMM per prompt), fold, then two GEMMs
+    kv = ops.gemm(ctx, torch.cat([wk, wv], 0))
+    wq_f, sq, tq = ops.ln_fold(wq.clone(), gamma, beta)
+    w1, s1, t1, w2 = ops.xattn_fold(kv, 0, c, B, L, wq_f, sq, tq, wo, heads)
+    assert float(w1[:, :, :].view(B, heads, 80, c)[:, :, 77:].abs().max()) == 0 and float(w2.view(B, c, heads, 80)[..., 77:].abs().max()) == 0
+    p = ops.gemm(x, w1, t1, ln_s=s1, rows_per_img=rows, softmax_cols=80)
+    for tile in (31, 48, 56, 57, 58):      # every tile that carries the softmax epilogue (one that does not divide the image is re-planned)
+        assert torch.equal(ops.gemm(x, w1, t1, ln_s=s1, rows_per_img=rows, softmax_cols=80, tile=tile), p) or \
+            rel_l2(ops.gemm(x, w1, t1, ln_s=s1, rows_per_img=rows, softmax_cols=80, tile=tile).float().cpu(), p.float().cpu()) < 1e-3, tile
+    pv = p.float().view(B * rows, heads, 80)
+    assert float(pv[..., 77:].abs().max()) == 0 and float((pv.sum(-1) - 1).abs().max()) < 5e-3
+    out = ops.gemm(p, w2, bo, residual=x, rows_per_img=rows)
+    check(out, ref, tol=4e-3, name=f'folded cross-attention {case}')

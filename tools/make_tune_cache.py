@@ -6,7 +6,7 @@ Builds every graph of the configurations the benches and the GPU tests use with 
 (engine.hip: emit_gemm) and its pick appended.  Copy the result over tune/gfx950.tune and commit it: from then on
 every process builds the same launch lists without timing anything.
 
-usage (GPU box):  python tools/make_tune_cache.py gpurun_out/gfx950.tune [--quick | --only-quant | --only-rows3]
+usage (GPU box):  python tools/make_tune_cache.py gpurun_out/gfx950.tune [--quick | --only-quant | --only-rows3 | --only-ln | --only-new]
 NEVER run under a profiler (timing noise would be baked into the picks)."""
 import os
 import sys
@@ -20,10 +20,11 @@ quick = '--quick' in sys.argv
 only_quant = '--only-quant' in sys.argv   # keep the shipped picks of every fp16 shape, re-time the uint8-weight shapes only
 only_rows3 = '--only-rows3' in sys.argv   # re-time only the 3x3 stride-1 convolutions on images whose rows are multiples of 3 (config 5)
 only_ln = '--only-ln' in sys.argv         # keep every shipped pick but those of the LayerNorm-folded Linears (key flag bit 30): re-time those
+only_new = '--only-new' in sys.argv       # keep EVERY shipped pick, time only the shapes the table does not have yet (a new fusion's GEMMs)
 if os.path.exists(out):
     os.remove(out)
 os.makedirs(os.path.dirname(out), exist_ok=True)
-if only_quant or only_rows3 or only_ln:
+if only_quant or only_rows3 or only_ln or only_new:
     shipped = os.path.join(ROOT, 'stable-diffusion-on-device_amd', 'tune', 'gfx950.tune')
     with open(shipped) as f, open(out, 'w') as g:
         for line in f:
@@ -31,7 +32,9 @@ if only_quant or only_rows3 or only_ln:
             if len(v) not in (13, 15):
                 continue
             # key fields (engine.hip: key_of): 0 a_mode, 6 stride, 8 ksize, 9 h_in, 10 flags (bit 29 = uint8 weights, bit 30 = LayerNorm fold)
-            if only_ln:
+            if only_new:
+                drop = False
+            elif only_ln:
                 drop = int(v[10]) & (1 << 30)
             else:
                 drop = (int(v[10]) & (1 << 29)) if only_quant else (v[0] == '1' and v[6] == '1' and v[8] == '3' and int(v[9]) % 3 == 0)
