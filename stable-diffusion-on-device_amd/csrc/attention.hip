@@ -425,76 +425,99 @@ hipError_t attn_dispatch(const AttnP& p, bool big, bool tr, hipStream_t st) {
 // element strides (the operands are slices of the K|V projection and of the weight matrices), rows / columns past the valid
 // range produce zeros.  fp16 in, fp32 accumulate, fp16 out; 16 outputs per thread from LDS tiles.
 struct FoldP {
-    const f16* a; const f16* b; f16* c;
-    long long a_bt0, a_bt1, b_bt0, b_bt1, c_bt0, c_bt1; // batch = (image, head): operand offsets per image / per head (elements)
-    int a_sm, a_sk, b_sn, b_sk, c_sm;                   // element strides (c: stride_n = 1)
-    int M, N, K, m_valid, n_valid, heads;
+    const f16* kv; int ld_kv, k_off, v_off, L, n_img;
+    const f16* wq; int ldq;
+    const float* sq; const float* tq;
+    const f16* wo; int ldwo;
+    int heads, d, C;
     float alpha;
+    f16* w1; float* s1; float* t1; f16* w2;
+    int tiles_c; // C / 80
+    int n_w;     // work items of W1 (and of W2): n_img * heads * tiles_c
 };
 constexpr int kFoldKMax = 160;
+// One launch per transformer block: workgroups [0, n_w) build 80 x 80 tiles of W1 (rows = a head's 80 key slots, columns = 80
+// input channels), [n_w, 2 n_w) tiles of W2 (rows = 80 output channels, columns = a head's key slots), the rest the fold
+// vectors.  Both products contract over the head dimension d (<= 160, zero-padded to the MFMA's 32): operands staged in LDS as
+// [row][k], v_mfma_f32_16x16x32_f16, 5 x 5 blocks of 16 x 16 per tile over 4 waves.
 __global__ __launch_bounds__(256) void xattn_fold_kernel(const FoldP p) {
-    __shared__ f16 sa[kFoldKMax][64 + 8], sb[kFoldKMax][64 + 8];
-    const int tid = threadIdx.x;
-    const int bt = blockIdx.z, img = bt / p.heads, h = bt - img * p.heads;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const f16* a = p.a + img * p.a_bt0 + h * p.a_bt1;
-    const f16* b = p.b + img * p.b_bt0 + h * p.b_bt1;
-    for (int idx = tid; idx < 64 * p.K; idx += 256) {
-        // the faster-running index follows the operand's unit stride, so that neighbouring threads read neighbouring halves
-        int ra, ka, rb, kb;
-        if (p.a_sk == 1) { ra = idx / p.K; ka = idx - ra * p.K; } else { ka = idx >> 6; ra = idx & 63; }
-        if (p.b_sk == 1) { rb = idx / p.K; kb = idx - rb * p.K; } else { kb = idx >> 6; rb = idx & 63; }
-        const int m = m0 + ra, n = n0 + rb;
-        sa[ka][ra] = m < p.m_valid ? a[(long long)m * p.a_sm + (long long)ka * p.a_sk] : (f16)0.f;
-        sb[kb][rb] = n < p.n_valid ? b[(long long)n * p.b_sn + (long long)kb * p.b_sk] : (f16)0.f;
-    }
-    __syncthreads();
-    const int tx = tid & 15, ty = tid >> 4;
-    float acc[4][4] = {};
-    for (int k = 0; k < p.K; ++k) {
-        const f16x4 av = *reinterpret_cast<const f16x4*>(&sa[k][ty * 4]);
-        const f16x4 bv = *reinterpret_cast<const f16x4*>(&sb[k][tx * 4]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = fmaf((float)av[i], (float)bv[j], acc[i][j]);
-    }
-    f16* c = p.c + img * p.c_bt0 + h * p.c_bt1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ty * 4 + i, n = n0 + tx * 4;
-        if (m < p.M && n + 3 < p.N) {
-            f16x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (f16)(p.alpha * acc[i][j]);
-            *reinterpret_cast<f16x4*>(c + (long long)m * p.c_sm + n) = o;
-        } else if (m < p.M) {
-            for (int j = 0; j < 4; ++j)
-                if (n + j < p.N) c[(long long)m * p.c_sm + n + j] = (f16)(p.alpha * acc[i][j]);
+    __shared__ __attribute__((aligned(16))) f16 sa[80][kFoldKMax + 8], sb[80][kFoldKMax + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NK = p.heads * 80, d = p.d;
+    int item = blockIdx.x;
+    if (item >= 2 * p.n_w) {
+        // fold vectors of the score GEMM: s1 = alpha * K_h . s_q, t1 = alpha * K_h . t_q; padding columns: s = 0 and a bias that
+        // the softmax turns into an exact zero
+        const int idx = (item - 2 * p.n_w) * 256 + tid;
+        if (idx >= p.n_img * NK) return;
+        const int j = idx % 80, bh = idx / 80, h = bh % p.heads, img = bh / p.heads;
+        if (j >= p.L) {
+            p.s1[idx] = 0.f;
+            p.t1[idx] = -30000.f;
+            return;
         }
-    }
-}
-// the LayerNorm-fold vectors of the score GEMM: s1 = alpha * K_h . s_q, t1 = alpha * K_h . t_q (s_q / t_q: those of the folded
-// to_q Linear); padding columns get s = 0 and a bias that the softmax turns into an exact zero
-__global__ __launch_bounds__(256) void xattn_fold_vec_kernel(const f16* kv, int ld_kv, int k_off, int L, const float* sq, const float* tq,
-                                                             int heads, int d, float alpha, float* s1, float* t1, int total) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int j = idx % 80, bh = idx / 80, h = bh % heads, img = bh / heads;
-    if (j >= L) {
-        s1[idx] = 0.f;
-        t1[idx] = -30000.f;
+        const f16* kr = p.kv + ((long long)img * p.L + j) * p.ld_kv + p.k_off + h * d;
+        float a = 0.f, b = 0.f;
+        for (int dd = 0; dd < d; ++dd) {
+            const float kval = (float)kr[dd];
+            a = fmaf(kval, p.sq[h * d + dd], a);
+            b = fmaf(kval, p.tq[h * d + dd], b);
+        }
+        p.s1[idx] = p.alpha * a;
+        p.t1[idx] = p.alpha * b;
         return;
     }
-    const f16* kr = kv + ((long long)img * L + j) * ld_kv + k_off + h * d;
-    float a = 0.f, b = 0.f;
-    for (int dd = 0; dd < d; ++dd) {
-        const float kval = (float)kr[dd];
-        a = fmaf(kval, sq[h * d + dd], a);
-        b = fmaf(kval, tq[h * d + dd], b);
+    const bool second = item >= p.n_w;
+    if (second) item -= p.n_w;
+    const int tc = item % p.tiles_c, bh = item / p.tiles_c, h = bh % p.heads, img = bh / p.heads;
+    const int KP = (d + 31) & ~31, kc = KP / 8;
+    // rows of K / V (key slots; slots past L and columns past d are zero) and of Wo: contiguous along k, 16-byte pieces
+    auto stage_rows = [&](f16 (*dst)[kFoldKMax + 8], const f16* base, long long row_stride, int valid_rows) {
+        for (int idx = tid; idx < 80 * kc; idx += 256) {
+            const int r = idx / kc, ch = idx - r * kc;
+            const f16x8 v = (r < valid_rows && ch * 8 < d) ? ldg8(base + (long long)r * row_stride + ch * 8) : zero8();
+            *reinterpret_cast<f16x8*>(&dst[r][ch * 8]) = v;
+        }
+    };
+    if (!second) {
+        stage_rows(sa, p.kv + (long long)img * p.L * p.ld_kv + p.k_off + h * d, p.ld_kv, p.L);
+        // Wq'[(h, k)][c]: contiguous along c -> transposed into [c][k]
+        for (int idx = tid; idx < KP * 10; idx += 256) {
+            const int k = idx / 10, ch = idx - k * 10;
+            const f16x8 v = k < d ? ldg8(p.wq + (long long)(h * d + k) * p.ldq + tc * 80 + ch * 8) : zero8();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sb[ch * 8 + e][k] = v[e];
+        }
+    } else {
+        stage_rows(sa, p.wo + (long long)(tc * 80) * p.ldwo + h * d, p.ldwo, 80);
+        stage_rows(sb, p.kv + (long long)img * p.L * p.ld_kv + p.v_off + h * d, p.ld_kv, p.L);
     }
-    s1[idx] = alpha * a;
-    t1[idx] = alpha * b;
+    __syncthreads();
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int rb = wave; rb < 5; rb += 4) { // (wave-uniform)
+        f32x4 acc[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < KP / 32; ++ks) {
+            const f16x8 fa = *reinterpret_cast<const f16x8*>(&sa[rb * 16 + fr][ks * 32 + fg * 8]);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const f16x8 fb = *reinterpret_cast<const f16x8*>(&sb[j * 16 + fr][ks * 32 + fg * 8]);
+                acc[j] = mfma16(fb, fa, acc[j]); // lane: row rb*16 + fr, columns j*16 + 4 fg + r
+            }
+        }
+        const int m = rb * 16 + fr;
+        f16* row = second ? p.w2 + ((long long)img * p.C + tc * 80 + m) * NK + h * 80
+                          : p.w1 + ((long long)(img * p.heads + h) * 80 + m) * p.C + tc * 80;
+        const float al = second ? 1.0f : p.alpha;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (f16)(al * acc[j][r]);
+            *reinterpret_cast<f16x4*>(row + j * 16 + fg * 4) = o;
+        }
+    }
 }
 
 } // namespace
@@ -537,28 +560,23 @@ extern "C" int sdod_xattn_fold_f16(const void* kv, int ld_kv, int k_off, int v_o
                                    void* s1, void* t1, void* w2, void* stream) {
     SDOD_TRY
     SDOD_REQUIRE(kv && wq && sq && tq && wo && w1 && s1 && t1 && w2, "null pointer");
-    SDOD_REQUIRE(n_img > 0 && heads > 0 && d > 0 && d <= kFoldKMax && d % 4 == 0 && L > 0 && L <= 80, "bad shape (d <= 160, L <= 80)");
+    SDOD_REQUIRE(n_img > 0 && heads > 0 && d > 0 && d <= kFoldKMax && d % 8 == 0 && L > 0 && L <= 80, "bad shape (d <= 160, d % 8 == 0, L <= 80)");
     const int C = heads * d, NK = heads * 80;
-    SDOD_REQUIRE(C % 4 == 0 && ldq >= C && ldwo >= C && ld_kv >= C, "bad strides");
-    hipStream_t st = (hipStream_t)stream;
-    const float alpha = scale * 1.4426950408889634f; // the softmax of the score GEMM's epilogue works in the exp2 domain
-    // W1[img][(h, j)][c] = alpha * sum_dd K[img, j, (h, dd)] * Wq'[(h, dd)][c]
+    SDOD_REQUIRE(C % 80 == 0 && ldq >= C && ldwo >= C && ld_kv >= C, "heads * d must be a multiple of 80; row strides >= heads * d");
+    SDOD_REQUIRE(ld_kv % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && ldq % 8 == 0 && ldwo % 8 == 0 &&
+                     (((uintptr_t)kv | (uintptr_t)wq | (uintptr_t)wo | (uintptr_t)w1 | (uintptr_t)w2) & 15) == 0,
+                 "operands must keep 16-byte alignment");
     FoldP p{};
-    p.a = (const f16*)kv + k_off; p.a_bt0 = (long long)L * ld_kv; p.a_bt1 = d; p.a_sm = ld_kv; p.a_sk = 1;
-    p.b = (const f16*)wq; p.b_bt0 = 0; p.b_bt1 = (long long)d * ldq; p.b_sn = 1; p.b_sk = ldq;
-    p.c = (f16*)w1; p.c_bt0 = (long long)NK * C; p.c_bt1 = (long long)80 * C; p.c_sm = C;
-    p.M = 80; p.N = C; p.K = d; p.m_valid = L; p.n_valid = C; p.heads = heads; p.alpha = alpha;
-    SDOD_LAUNCH(xattn_fold_kernel, dim3((C + 63) / 64, 2, n_img * heads), dim3(256), 0, st, p);
-    const int total = n_img * NK;
-    SDOD_LAUNCH(xattn_fold_vec_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const f16*)kv, ld_kv, k_off, L, (const float*)sq,
-                (const float*)tq, heads, d, alpha, (float*)s1, (float*)t1, total);
-    // W2[img][c][(h, j)] = sum_dd Wo[c][(h, dd)] * V[img, j, (h, dd)]
-    FoldP q{};
-    q.a = (const f16*)wo; q.a_bt0 = 0; q.a_bt1 = d; q.a_sm = ldwo; q.a_sk = 1;
-    q.b = (const f16*)kv + v_off; q.b_bt0 = (long long)L * ld_kv; q.b_bt1 = d; q.b_sn = ld_kv; q.b_sk = 1;
-    q.c = (f16*)w2; q.c_bt0 = (long long)C * NK; q.c_bt1 = 80; q.c_sm = NK;
-    q.M = C; q.N = 80; q.K = d; q.m_valid = C; q.n_valid = L; q.heads = heads; q.alpha = 1.0f;
-    SDOD_LAUNCH(xattn_fold_kernel, dim3(2, (C + 63) / 64, n_img * heads), dim3(256), 0, st, q);
+    p.kv = (const f16*)kv; p.ld_kv = ld_kv; p.k_off = k_off; p.v_off = v_off; p.L = L; p.n_img = n_img;
+    p.wq = (const f16*)wq; p.ldq = ldq; p.sq = (const float*)sq; p.tq = (const float*)tq;
+    p.wo = (const f16*)wo; p.ldwo = ldwo;
+    p.heads = heads; p.d = d; p.C = C;
+    p.alpha = scale * 1.4426950408889634f; // the softmax of the score GEMM's epilogue works in the exp2 domain
+    p.w1 = (f16*)w1; p.s1 = (float*)s1; p.t1 = (float*)t1; p.w2 = (f16*)w2;
+    p.tiles_c = C / 80;
+    p.n_w = n_img * heads * p.tiles_c;
+    const int blocks = 2 * p.n_w + (n_img * NK + 255) / 256;
+    SDOD_LAUNCH(xattn_fold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     SDOD_HIP_CHECK(hipGetLastError());
     return 0;
     SDOD_CATCH
