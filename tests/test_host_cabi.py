@@ -269,7 +269,7 @@ def test_apanel_tile_eligibility_without_a_gpu():
     assert lib.sdod_gemm_plan(ctypes.byref(d), ctypes.byref(t), ctypes.byref(s)) == 0 and (t.value, s.value) == (53, 1)
     info = (ctypes.c_int * 7)()
     assert lib.sdod_gemm_tile_info(54, info) == 0 and list(info)[:4] == [64, 128, 2, 2] and info[5] == 3
-    assert lib.sdod_gemm_num_tiles() == 58
+    assert lib.sdod_gemm_num_tiles() == 60
     assert lib.sdod_gemm_tile_info(57, info) == 0 and list(info)[:6] == [128, 160, 2, 2, 3, 1]   # ring tiles for the softmax-epilogue GEMM
 
 

@@ -19,8 +19,8 @@ for hw, c in ((64, 320), (32, 640), (16, 1280), (8, 1280)):
     w2 = (torch.randn(B, c, 640) / 25).half().to(d); bo = torch.randn(c).to(d)
     p = torch.empty(B * rows, 640, dtype=torch.float16, device=d); out = torch.empty(B * rows, c, dtype=torch.float16, device=d)
     line = f'{hw}x{hw} C{c}: scores'
-    for tile in (31, 48, 56, 57, 58, 21, 22):
-        for sm, ln in ((80, True), (0, True), (0, False)):
+    for tile in (31, 48, 56, 57, 58, 59, 60):
+        for sm, ln in ((80, True),):
             try:
                 f = lambda: ops.gemm(x, w1, t1, ln_s=s1 if ln else None, rows_per_img=rows, softmax_cols=sm, tile=tile, out=p)
                 f()
