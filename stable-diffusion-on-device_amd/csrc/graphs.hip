@@ -619,26 +619,24 @@ void Graph::build_clip() {
         const int f1w = P(pfx + (oc ? ".mlp.c_fc.weight" : ".mlp.fc1.weight"), {inter, D}, PK_LINEAR), f1b = P(pfx + (oc ? ".mlp.c_fc.bias" : ".mlp.fc1.bias"), {inter}, PK_VEC);
         const int f2w = P(pfx + (oc ? ".mlp.c_proj.weight" : ".mlp.fc2.weight"), {D, inter}, PK_LINEAR), f2b = P(pfx + (oc ? ".mlp.c_proj.bias" : ".mlp.fc2.bias"), {D}, PK_VEC);
         if (mode_ == DECLARE) continue;
-        Act n1 = layer_norm(x, l1w, l1b, 1e-5f);
+        // both LayerNorms of a block are folded into the Linear that consumes them (as in the UNet's transformer blocks): no
+        // LayerNorm launch, no normalised tensor -- 2 x text_layers launches fewer per prompt
         f16* qkv = alloc((size_t)rows * 3 * D);
         if (oc) {
-            GemmOpt o; o.bias = qkvb;
-            linear(n1.p, rows, D, qkvw, 3 * D, qkv, o);
+            GemmOpt o; o.bias = qkvb; o.ln_w = l1w; o.ln_b = l1b;
+            linear(x.p, rows, D, qkvw, 3 * D, qkv, o);
         } else {
-            GemmOpt o; o.bias_raw = reinterpret_cast<const float*>(group_base(gb));
-            linear_raw(n1.p, rows, D, reinterpret_cast<const f16*>(group_base(gw)), D, 3 * D, qkv, o);
+            GemmOpt o; o.bias_raw = reinterpret_cast<const float*>(group_base(gb)); o.ln_w = l1w; o.ln_b = l1b;
+            linear_raw(x.p, rows, D, reinterpret_cast<const f16*>(group_base(gw)), D, 3 * D, qkv, o);
         }
-        release(n1);
         f16* a = alloc((size_t)rows * D);
         attention(qkv, qkv + D, qkv + 2 * D, a, B, heads, L, L, D / heads, 3 * D, 3 * D, 3 * D, D, true);
         release(qkv);
         Act x1 = act(B, 1, L, D);
         { GemmOpt o; o.bias = ob; o.residual = x.p; linear(a, rows, D, ow, D, x1.p, o); }
         release(a); release(x);
-        Act n2 = layer_norm(x1, l2w, l2b, 1e-5f);
         f16* f = alloc((size_t)rows * inter);
-        { GemmOpt o; o.bias = f1b; o.act = oc ? SDOD_ACT_GELU : SDOD_ACT_QUICK_GELU; linear(n2.p, rows, D, f1w, inter, f, o); }
-        release(n2);
+        { GemmOpt o; o.bias = f1b; o.act = oc ? SDOD_ACT_GELU : SDOD_ACT_QUICK_GELU; o.ln_w = l2w; o.ln_b = l2b; linear(x1.p, rows, D, f1w, inter, f, o); }
         Act x2 = act(B, 1, L, D);
         { GemmOpt o; o.bias = f2b; o.residual = x1.p; linear(f, rows, inter, f2w, D, x2.p, o); }
         release(f); release(x1);
