@@ -258,6 +258,9 @@ SDOD_API int sdod_act_f16(const void* x, void* y, size_t n, int act, void* strea
 SDOD_API int sdod_add_f16(const void* a, const void* b, void* y, size_t n, void* stream);
 SDOD_API int sdod_concat_channels_f16(const void* a, const void* b, void* y, size_t rows, int c0, int c1, void* stream);
 SDOD_API int sdod_im2col3x3_small_f16(const void* x, void* y, int n_img, int h, int w, int c, int kpad, void* stream);
+/* sdod_latent_prep_f16 (w = NULL) followed by sdod_im2col3x3_small_f16 in one launch: x NCHW fp32 [n][c][h][w] -> the im2col matrix
+ * [n*h*w][kpad] fp16 of a 3x3 pad-1 convolution (k = tap * c + channel, zero beyond 9c), values (fp16)(x * scale); kpad % 8 == 0 */
+SDOD_API int sdod_latent_im2col_f16(const float* x, void* y, int n_img, int h, int w, int c, int kpad, float scale, void* stream);
 SDOD_API int sdod_nchw_f32_to_nhwc_f16(const float* x, void* y, int n, int c, int hw, float scale, void* stream);
 /* y(NHWC fp16)[img][pix][o] = sum_c w[o][c]*(scale*x(NCHW fp32)[img][c][pix]) + b[o]; w/b fp32 [c][c]/[c] or NULL
  * (identity).  Folds ldm's z/0.18215 and first_stage_model.post_quant_conv into the layout change. */

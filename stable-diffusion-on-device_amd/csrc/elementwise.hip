@@ -99,6 +99,34 @@ __global__ void im2col_small_kernel(const f16* x, f16* y, int n_img, int h, int 
     }
 }
 
+// latent_prep (NCHW fp32 -> fp16, scaled) and im2col_small in one pass: the UNet's input convolution (Cin = 4) as a K = 64 GEMM
+// needs only the im2col matrix, so the NHWC copy in between is never written.  8 consecutive k per thread (one 16-byte store).
+__global__ void latent_im2col_kernel(const float* x, f16* y, int n_img, int h, int w, int c, int kpad, float scale) {
+    const int kp8 = kpad / 8;
+    const size_t total = (size_t)n_img * h * w * kp8;
+    GRID_STRIDE(i, total) {
+        const size_t row = i / kp8;
+        const int k0 = (int)(i - row * kp8) * 8;
+        const int img = (int)(row / ((size_t)h * w));
+        const int rem = (int)(row - (size_t)img * h * w);
+        const int oy = rem / w, ox = rem - oy * w;
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            float f = 0.f;
+            if (k < 9 * c) {
+                const int tap = k / c, ch = k - tap * c;
+                const int r = tap / 3, s2 = tap - r * 3;
+                const int yy = oy + r - 1, xx = ox + s2 - 1;
+                if (yy >= 0 && yy < h && xx >= 0 && xx < w) f = 0.f + x[(((size_t)img * c + ch) * h + yy) * w + xx] * scale;
+            }
+            v[e] = (f16)f;
+        }
+        *reinterpret_cast<f16x8*>(y + row * kpad + k0) = v;
+    }
+}
+
 __global__ void nchw_to_nhwc_kernel(const float* x, f16* y, int n, int c, int hw, float scale) {
     const size_t total = (size_t)n * c * hw;
     GRID_STRIDE(i, total) { // i indexes the NHWC output
@@ -392,6 +420,14 @@ extern "C" int sdod_im2col3x3_small_f16(const void* x, void* y, int n_img, int h
     SDOD_TRY
     SDOD_REQUIRE(x && y && n_img > 0 && h > 0 && w > 0 && c > 0 && kpad >= 9 * c, "bad argument");
     LAUNCH(im2col_small_kernel, (size_t)n_img * h * w * kpad, stream, (const f16*)x, (f16*)y, n_img, h, w, c, kpad);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_latent_im2col_f16(const float* x, void* y, int n_img, int h, int w, int c, int kpad, float scale, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(x && y && n_img > 0 && h > 0 && w > 0 && c > 0 && kpad >= 9 * c && kpad % 8 == 0 && ((uintptr_t)y & 15) == 0, "bad argument");
+    LAUNCH(latent_im2col_kernel, (size_t)n_img * h * w * (kpad / 8), stream, x, (f16*)y, n_img, h, w, c, kpad, scale);
     return 0;
     SDOD_CATCH
 }

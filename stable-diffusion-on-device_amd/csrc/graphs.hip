@@ -333,13 +333,11 @@ void Graph::build_unet() {
 
     // input conv (Cin = 4): im2col to K = 64, then the GEMM
     const int ciw = P("input_blocks.0.0.weight", {MC, LC, 3, 3}, PK_CONV3_SMALL), cib = P("input_blocks.0.0.bias", {MC}, PK_VEC);
-    Act x_nhwc = act(B, H, Wd, LC);
-    emit([=](hipStream_t st) { check_rc2(sdod_latent_prep_f16(x_in, nullptr, nullptr, x_nhwc.p, B, LC, H * Wd, 1.0f, st)); });
     f16* cols = alloc((size_t)B * H * Wd * 64);
-    emit([=](hipStream_t st) { check_rc2(sdod_im2col3x3_small_f16(x_nhwc.p, cols, B, H, Wd, LC, 64, st)); });
+    emit([=](hipStream_t st) { check_rc2(sdod_latent_im2col_f16(x_in, cols, B, H, Wd, LC, 64, 1.0f, st)); });
     Act h = act(B, H, Wd, MC);
     { GemmOpt o; o.bias = cib; linear(cols, B * H * Wd, 64, ciw, MC, h.p, o); }
-    release(cols); release(x_nhwc);
+    release(cols);
 
     std::vector<Act> hs;
     hs.push_back(h);

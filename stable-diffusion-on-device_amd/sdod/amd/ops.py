@@ -346,6 +346,16 @@ def im2col3x3_small(x, kpad=64):
     return out
 
 
+def latent_im2col(x, kpad=64, scale=1.0):
+    """NCHW fp32 latent -> im2col matrix [n*h*w, kpad] fp16 of a 3x3 pad-1 convolution (the UNet's input conv as a K = 64 GEMM)"""
+    lib = _lib.hip()
+    _req(x, torch.float32, 'x')
+    n, c, h, w = x.shape
+    out = torch.empty((n * h * w, kpad), dtype=torch.float16, device=x.device)
+    check(lib.sdod_latent_im2col_f16(_p(x), _p(out), n, h, w, c, kpad, scale, _stream()))
+    return out
+
+
 def nchw_f32_to_nhwc_f16(x, scale=1.0):
     lib = _lib.hip()
     _req(x, torch.float32, 'x')

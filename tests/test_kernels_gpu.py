@@ -1043,3 +1043,13 @@ def test_folded_cross_attention_matches_linear_attention_linear(case):
     assert float(pv[..., 77:].abs().max()) == 0 and float((pv.sum(-1) - 1).abs().max()) < 5e-3
     out = ops.gemm(p, w2, bo, residual=x, rows_per_img=rows)
     check(out, ref, tol=4e-3, name=f'folded cross-attention {case}')
+
+
+def test_latent_im2col_equals_latent_prep_then_im2col():
+    """sdod_latent_im2col_f16 (the UNet's input convolution: NCHW fp32 latent -> K = 64 im2col matrix in one launch) against the
+    two launches it replaces, bit for bit, odd sizes included"""
+    from sdod.amd import ops
+    for n, c, h, w, scale in ((2, 4, 64, 64, 1.0), (1, 4, 17, 9, 0.5), (3, 4, 8, 8, 1.0 / 0.18215)):
+        x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(n * 100 + h)).cuda()
+        ref = ops.im2col3x3_small(ops.nchw_f32_to_nhwc_f16(x, scale), 64)
+        assert torch.equal(ops.latent_im2col(x, 64, scale), ref), (n, c, h, w)
