@@ -635,7 +635,9 @@ void Graph::flush_pending() {
 void Graph::emit_gemm(sdod_gemm_desc d) {
     settle();
     if (mode_ == DECLARE) return;
-    const bool tune = autotune_enabled() && d.N > 16;
+    // (N <= 16: the skinny default tile -- except the UNet's output convolution, 320 -> 4 channels, where a halo-patch tile without
+    // split-K beats it by 7 us and a reduce launch: tools/convout_bench.py)
+    const bool tune = autotune_enabled() && (d.N > 16 || (d.a_mode == SDOD_A_CONV3X3 && d.ksize != 1 && d.N % 4 == 0));
     if (tune) {
         for (int t : kCandidates) {
             sdod_gemm_desc c = d;
