@@ -60,8 +60,12 @@ SDOD_DEVICE void static_for(F&& f) {
     }
 }
 
-template <int D, int QT, bool TR>
-__global__ __launch_bounds__(256, (attn_min_waves<D, QT>())) void attn_kernel(const AttnP p) {
+// KVS = key/value split INSIDE the workgroup: KVS groups of four waves own the SAME 64*QT query rows and every KVS-th key tile
+// (own LDS stages), and merge their (max, sum, O) through LDS at the end.  For the launches whose grid is one workgroup per CU
+// (d = 80 at 32x32: 256 workgroups) the tile loop is a latency-bound chain on one wave per SIMD; a second group halves the
+// chain and doubles the waves that hide it, at the same K/V traffic.
+template <int D, int QT, bool TR, int KVS = 1>
+__global__ __launch_bounds__(256 * KVS, (attn_min_waves<D, QT>())) void attn_kernel(const AttnP p) {
     constexpr int DP = ((D + 31) / 32) * 32; // QK^T contraction, padded to MFMA K=32
     constexpr int KSTEPS = DP / 32;
     constexpr int DV = ((D + 15) / 16) * 16; // PV output columns, padded to 16
@@ -78,9 +82,10 @@ __global__ __launch_bounds__(256, (attn_min_waves<D, QT>())) void attn_kernel(co
     static_assert(D % 8 == 0, "head dim must be a multiple of 8");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    f16* smem = reinterpret_cast<f16*>(smem_raw);
+    const int grp = KVS > 1 ? (int)(threadIdx.x >> 8) : 0; // key/value group of this wave (wave-uniform)
+    f16* smem = reinterpret_cast<f16*>(smem_raw) + (size_t)grp * 2 * STAGE;
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 255; // thread inside its group
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int g = lane >> 4;   // lane group 0..3
@@ -333,16 +338,22 @@ __global__ __launch_bounds__(256, (attn_min_waves<D, QT>())) void attn_kernel(co
     // three LDS stages, K fragments read behind the previous barrier: 220 VGPRs, 8 % SLOWER (123 vs 113 us at 4096^2, d = 40:
     // the compiler serialises the longer body no better, and the third LDS stage costs occupancy where B >= 4 would have
     // used it).  Removed; profiles/r03_attention_occupancy.txt keeps the numbers.)
-    if (NT > 0) {
-        load_tile(0);
+    if (grp < NT) {
+        load_tile(grp);
         store_tile(0);
     }
     __syncthreads();
-    for (int t = 0; t < NT; ++t) {
-        const int cur = t & 1;
-        const bool has_next = t + 1 < NT;
+    const int NTG = (NT + KVS - 1) / KVS; // every group runs the same number of iterations (the barriers are workgroup-wide)
+    for (int it = 0; it < NTG; ++it) {
+        const int t = it * KVS + grp;
+        const int cur = it & 1;
+        const bool has_next = t + KVS < NT;
         const f16* sK = smem + cur * STAGE;
         const f16* sV = sK + KT * KSTR;
+        if (t >= NT) { // (KVS > 1: a ragged last round)
+            __syncthreads();
+            continue;
+        }
         // ---- fragments of the tile first: K for S^T = K . Q^T and (transposed) V for O^T += V^T . P^T are read ONCE and kept
         // in registers for both query tiles; the V reads are issued here so that they land during the softmax
         // (D = 160 would need 160 registers for them and drop to one wave per SIMD: it reads at the point of use)
@@ -357,12 +368,45 @@ __global__ __launch_bounds__(256, (attn_min_waves<D, QT>())) void attn_kernel(co
         // the next tile's K/V are requested HERE, behind the fragment reads and the QK^T issue: requested at the top of the
         // iteration, the compiler's wait-count pass (it cannot count loads under divergent predicates) put a vmcnt(0) in front
         // of the first MFMA, i.e. the full global-load latency on the critical path of every tile
-        if (has_next && !(abl & 1)) load_tile(t + 1);
+        if (has_next && !(abl & 1)) load_tile(t + KVS);
         static_for<QT>([&](auto a_c) { softmax_pv(a_c, t, s[decltype(a_c)::value], vfr, sV); });
         if (has_next) store_tile(cur ^ 1);
         __syncthreads();
     }
 
+    if constexpr (KVS > 1) {
+        // merge the groups' partial softmaxes: group g > 0 parks (m, l, O) of its lanes in LDS ([value][thread]: conflict-free),
+        // group 0 folds them in -- the usual online-softmax combination, once -- and stores
+        static_assert(KVS == 2, "the merge below handles two groups");
+        float* mrg = reinterpret_cast<float*>(smem_raw);
+        constexpr int NV = QT * (2 + NDT * 4);
+        static_assert((size_t)NV * 256 * sizeof(float) <= (size_t)KVS * 2 * STAGE * sizeof(f16), "merge buffer fits the staging LDS");
+        if (grp == 1) {
+#pragma unroll
+            for (int a = 0; a < QT; ++a) {
+                mrg[(a * (2 + NDT * 4) + 0) * 256 + tid] = m_run[a];
+                mrg[(a * (2 + NDT * 4) + 1) * 256 + tid] = l_run[a];
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mrg[(a * (2 + NDT * 4) + 2 + dt * 4 + r) * 256 + tid] = o[a][dt][r];
+            }
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int a = 0; a < QT; ++a) {
+            const float m1 = mrg[(a * (2 + NDT * 4) + 0) * 256 + tid], l1 = mrg[(a * (2 + NDT * 4) + 1) * 256 + tid];
+            const float m = fmaxf(m_run[a], m1);
+            const float a0 = __builtin_amdgcn_exp2f(m_run[a] - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+            l_run[a] = l_run[a] * a0 + l1 * a1;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[a][dt][r] = o[a][dt][r] * a0 + mrg[(a * (2 + NDT * 4) + 2 + dt * 4 + r) * 256 + tid] * a1;
+            m_run[a] = m;
+        }
+    }
     // ---- normalise and store: lane holds O[q = qrow][dv = dt*16 + 4g + r]
 #pragma unroll
     for (int a = 0; a < QT; ++a) {
@@ -392,19 +436,20 @@ __global__ __launch_bounds__(256, (attn_min_waves<D, QT>())) void attn_kernel(co
     }
 }
 
-template <int D, int QT, bool TR>
+template <int D, int QT, bool TR, int KVS = 1>
 hipError_t attn_launch(const AttnP& p, hipStream_t st) {
     constexpr int DP = ((D + 31) / 32) * 32;
     constexpr int DV = ((D + 15) / 16) * 16;
-    constexpr size_t smem = (size_t)2 * 64 * (DP + 8 + odd16(DV)) * sizeof(f16);
+    constexpr size_t smem = (size_t)KVS * 2 * 64 * (DP + 8 + odd16(DV)) * sizeof(f16);
+    static_assert(smem <= 160 * 1024, "LDS");
     static std::atomic<unsigned long long> attr_devs{0};
     if (sdod::first_use_on_device(attr_devs)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, QT, TR>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, QT, TR, KVS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
     }
     dim3 grid(((p.Lq + 64 * QT - 1) / (64 * QT)) * p.H * p.B);
-    SDOD_LAUNCH((attn_kernel<D, QT, TR>), grid, dim3(256), smem, st, p);
+    SDOD_LAUNCH((attn_kernel<D, QT, TR, KVS>), grid, dim3(256 * KVS), smem, st, p);
     return hipGetLastError();
 }
 
@@ -547,7 +592,15 @@ extern "C" int sdod_attention_f16(const void* q, const void* k, const void* v, v
     switch (d) {
     case 40: e = attn_dispatch<40>(p, big, tr, st); break;
     case 64: e = attn_dispatch<64>(p, big, tr, st); break;
-    case 80: e = attn_dispatch<80>(p, big, tr, st); break;
+    case 80: {
+        // one workgroup per CU or less and at least four key tiles: split the keys inside the workgroup (two groups of four waves)
+        // (19.4 vs 21.3 us at 32x32, tools/attn_bench.py; SDOD_ATTN_KVS=0 keeps the four-wave form)
+        static const bool kvs_off = [] { const char* e2 = std::getenv("SDOD_ATTN_KVS"); return e2 && e2[0] == '0'; }();
+        const long long wgs = (long long)((lq + 63) / 64) * heads * batch;
+        if (!big && tr && !kvs_off && !causal && wgs <= 512 && lk >= 256) e = attn_launch<80, 1, true, 2>(p, st);
+        else e = attn_dispatch<80>(p, big, tr, st);
+        break;
+    }
     default: e = attn_dispatch<160>(p, false, tr, st); break;
     }
     SDOD_HIP_CHECK(e);

@@ -856,6 +856,9 @@ def attn_ref(q, k, v, heads, causal=False):
     (2, 8, 256, 256, 160, False), (2, 8, 64, 64, 160, False), (2, 8, 4096, 77, 40, False),
     (2, 8, 1024, 77, 80, False), (2, 8, 256, 77, 160, False), (2, 12, 77, 77, 64, True), (1, 3, 200, 333, 64, False),
     (1, 2, 100, 100, 80, True),
+    # d = 80 on a small grid: the key/value split inside the workgroup (two groups of four waves, merged through LDS) -- an even
+    # number of key tiles, an odd one (ragged last round), a ragged last tile, and one group with a single tile
+    (1, 4, 512, 1024, 80, False), (2, 3, 200, 333, 80, False), (1, 2, 64, 257, 80, False), (1, 8, 1024, 320, 80, False),
 ])
 @pytest.mark.parametrize('use_tr', [True, False])
 def test_attention(b, heads, lq, lk, d, causal, use_tr):
