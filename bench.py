@@ -249,13 +249,26 @@ def main():
     temb = pipe.time_embeddings(np.asarray([951.0], np.float32))
     x = x_T.clone()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # one step of the sampler loop as sample_plms runs it from its second step on: UNet replay, then ONE launch for guidance +
+    # multistep combination + DDIM update + staging of the next evaluation's inputs (ops.plms_update)
+    from sdod.amd.samplers import PlmsSchedule, PLMS_ORDERS
+    sch = PlmsSchedule(20)
+    coefs, div = PLMS_ORDERS[1]
+    old1 = torch.zeros_like(x)
+
+    def one_step():
+        pipe.unet.execute(pipe.use_hip_graph, static_unchanged=not pipe._ctx_fresh)
+        pipe._ctx_fresh = False
+        eps = pipe._exchange_halves(pipe.unet.eps) if pipe.cfg_split else pipe.unet.eps
+        return ops.plms_update(eps, x, [old1], coefs, div, sch.coef(10), 7.5, mode=1, stage=(pipe.unet.x, temb[0], pipe.unet.temb))
+
+    ops.stage_unet_inputs(x, pipe.unet.x, temb[0], pipe.unet.temb)
     for _ in range(2):
-        e = pipe._eps(x, temb[0], 7.5, 1)
+        one_step()
     reps = 10
     ev0.record()
     for _ in range(reps):
-        e = pipe._eps(x, temb[0], 7.5, 1)
-        ops.ddim_step(x.clone(), e, 0.5, 0.5, 0.5, 0.5)
+        one_step()
     ev1.record()
     torch.cuda.synchronize()
     unet_step_ms = ev0.elapsed_time(ev1) / reps

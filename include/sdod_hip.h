@@ -300,6 +300,25 @@ SDOD_API int sdod_ddim_step_f32(float* x, const float* e, size_t count, float sq
 /* out = (c0*e0 + c1*e1 + c2*e2 + c3*e3)/div, left to right (PLMS Adams-Bashforth combinations); e1..e3 may be NULL */
 SDOD_API int sdod_lincomb4_f32(float* out, const float* e0, const float* e1, const float* e2, const float* e3,
                                float c0, float c1, float c2, float c3, float div, size_t count, void* stream);
+
+/* One PLMS step behind a UNet evaluation in one launch (Python host loop, sdod/amd/pipeline.py: sample_plms; the reference's
+ * sampler is ldm's PLMSSampler.p_sample_plms): e_t = CFG(eps) [sdod_cfg_combine; optional v -> eps conversion
+ * e_t = vc0 * e + vc1 * x], e' = (c0 e_t + c1 old1 + c2 old2 + c3 old3) / div [sdod_lincomb4_f32], x <- DDIM step with e'
+ * [sdod_ddim_step_f32], then the next evaluation's inputs [sdod_stage_unet_inputs: x into x_stage[stage_reps][..], temb_row into
+ * temb_dst[temb_reps][..]]; the same fp32 operations in the same order as those four calls, bit for bit.  old1..3, x_stage,
+ * temb_row may be NULL. */
+typedef struct sdod_plms_update_args {
+    const void* eps_nhwc;   /* fp16 [2n][hw][c] */
+    float* e_out;           /* fp32 [n][c][hw]: e_t, kept by the caller as history */
+    float* x;               /* fp32 [n][c][hw], updated in place */
+    const float* old1; const float* old2; const float* old3;
+    float* x_stage;         /* fp32 [stage_reps][n][c][hw] or NULL */
+    const void* temb_row;   /* fp16 [temb_width] or NULL */
+    void* temb_dst;         /* fp16 [temb_reps][temb_width] */
+    int n, c, hw, uncond_first, mode, v_pred, stage_reps, temb_width, temb_reps;
+    float guidance, vc0, vc1, c0, c1, c2, c3, div, sqrt_one_minus_at, sqrt_at, sqrt_a_prev, dir_coef;
+} sdod_plms_update_args;
+SDOD_API int sdod_plms_update(const sdod_plms_update_args* a, void* stream);
 /* img: fp16 NHWC [n][hw][3] -> uint8 HWC per image, f = a*v+b, truncating cast:
  *   mode 0: clamp(255*f, 0, 255)   (context.cpp:392-395; a=1,b=0 is the reference's already-[0,1] convention)
  *   mode 1: 255*clamp(f, 0, 1)     (ldm txt2img with a=0.5, b=0.5) */

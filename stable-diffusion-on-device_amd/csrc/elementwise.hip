@@ -328,6 +328,50 @@ __global__ void to_u8_kernel(const f16* img, uint8_t* out, size_t count, float a
 // ---- sampler-loop staging: the UNet graph's inputs for one guided evaluation in ONE launch.  The latent x (fp32 NCHW, n
 // images) is written `reps` times back to back (uncond rows, then cond rows) and the projected time-conditioning row is
 // broadcast to every batch row -- the three strided copies the host loop used to issue per evaluation.
+// One PLMS step behind a UNet evaluation in ONE launch: classifier-free guidance (cfg_kernel's arithmetic), the optional
+// v -> eps conversion, the multistep combination (lincomb4_kernel), the DDIM update (ddim_step_kernel) and the staging of the
+// next evaluation's inputs (stage_unet_inputs_kernel) -- the same fp32 operations in the same order, so the results are the
+// bits the four launches produce (tests/test_kernels_gpu.py::test_plms_update_equals_the_four_launches).
+__global__ void plms_update_kernel(const sdod_plms_update_args a) {
+    const size_t lat = (size_t)a.n * a.c * a.hw;
+    const size_t nt = a.temb_row ? (size_t)a.temb_width * a.temb_reps : 0;
+    const f16* eps = (const f16*)a.eps_nhwc;
+    GRID_STRIDE(i, lat + nt) {
+        if (i >= lat) {
+            ((f16*)a.temb_dst)[i - lat] = ((const f16*)a.temb_row)[(i - lat) % a.temb_width];
+            continue;
+        }
+        const int pix = (int)(i % a.hw);
+        const size_t t = i / a.hw;
+        const int ch = (int)(t % a.c);
+        const int img = (int)(t / a.c);
+        const int iu = a.uncond_first ? img : img + a.n;
+        const int ic = a.uncond_first ? img + a.n : img;
+        const float eu = (float)eps[((size_t)iu * a.hw + pix) * a.c + ch];
+        const float ec = (float)eps[((size_t)ic * a.hw + pix) * a.c + ch];
+        float e;
+        if (a.mode == 0) {
+            e = mul_rn(ec, a.guidance);
+            e = add_rn(e, mul_rn(eu, sub_rn(1.0f, a.guidance)));
+        } else {
+            e = add_rn(eu, mul_rn(a.guidance, sub_rn(ec, eu)));
+        }
+        const float xv = a.x[i];
+        if (a.v_pred) e = div_rn(add_rn(mul_rn(a.vc0, e), mul_rn(a.vc1, xv)), 1.0f); // lincomb4([e, x], [vc0, vc1], 1)
+        a.e_out[i] = e;
+        float v = mul_rn(a.c0, e);
+        if (a.old1) v = add_rn(v, mul_rn(a.c1, a.old1[i]));
+        if (a.old2) v = add_rn(v, mul_rn(a.c2, a.old2[i]));
+        if (a.old3) v = add_rn(v, mul_rn(a.c3, a.old3[i]));
+        const float ep = div_rn(v, a.div);
+        const float x0 = div_rn(sub_rn(xv, mul_rn(a.sqrt_one_minus_at, ep)), a.sqrt_at);
+        const float xn = add_rn(mul_rn(a.sqrt_a_prev, x0), mul_rn(a.dir_coef, ep));
+        a.x[i] = xn;
+        if (a.x_stage)
+            for (int r = 0; r < a.stage_reps; ++r) a.x_stage[(size_t)r * lat + i] = xn;
+    }
+}
+
 __global__ void stage_unet_inputs_kernel(const float* x, float* x_dst, size_t lat, int reps, const f16* temb_row, f16* temb_dst,
                                          size_t temb_w, int temb_reps) {
     const size_t nx = lat * (size_t)reps, nt = temb_w * (size_t)temb_reps;
@@ -491,6 +535,18 @@ extern "C" int sdod_stage_unet_inputs(const float* x, float* x_dst, size_t lat_c
     SDOD_REQUIRE((temb_row && temb_dst && temb_width > 0 && temb_reps > 0) || temb_reps == 0, "bad time-conditioning argument");
     LAUNCH(stage_unet_inputs_kernel, lat_count * (size_t)reps + temb_width * (size_t)temb_reps, stream, x, x_dst, lat_count, reps,
            (const f16*)temb_row, (f16*)temb_dst, temb_width, temb_reps);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_plms_update(const sdod_plms_update_args* a, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(a && a->eps_nhwc && a->e_out && a->x && a->n > 0 && a->c > 0 && a->hw > 0 && (a->mode == 0 || a->mode == 1) && a->div != 0.0f,
+                 "bad argument");
+    SDOD_REQUIRE(!a->x_stage || a->stage_reps > 0, "x_stage needs stage_reps");
+    SDOD_REQUIRE(!a->temb_row || (a->temb_dst && a->temb_width > 0 && a->temb_reps > 0), "bad time-conditioning argument");
+    const size_t work = (size_t)a->n * a->c * a->hw + (a->temb_row ? (size_t)a->temb_width * a->temb_reps : 0);
+    LAUNCH(plms_update_kernel, work, stream, *a);
     return 0;
     SDOD_CATCH
 }

@@ -405,6 +405,38 @@ def cfg_combine(eps_nhwc, guidance, uncond_first=True, mode=1):
     return out
 
 
+def plms_update(eps_nhwc, x, old, coefs, div, ddim, guidance, mode=1, v_coef=None, stage=None):
+    """one PLMS step in one launch (include/sdod_hip.h: sdod_plms_update): CFG of eps (+ v -> eps with v_coef = (c_e, c_x)),
+    e' = (coefs[0] e_t + coefs[1:] . old) / div, DDIM update of x in place with ddim = schedule.coef(index), and -- with
+    stage = (x_dst, temb_row, temb_dst) -- the next evaluation's inputs.  Returns e_t (fp32 [n, c, ...])."""
+    lib = _lib.hip()
+    _req(eps_nhwc, torch.float16, 'eps'); _req(x, torch.float32, 'x')
+    n2, c = eps_nhwc.shape[0], eps_nhwc.shape[-1]
+    n = n2 // 2
+    hw = eps_nhwc.numel() // (n2 * c)
+    assert x.numel() == n * c * hw and len(old) <= 3 and len(coefs) == len(old) + 1
+    e_out = torch.empty_like(x)
+    a = _lib.PlmsUpdateArgs()
+    a.eps_nhwc, a.e_out, a.x = _p(eps_nhwc), _p(e_out), _p(x)
+    olds = list(old) + [None] * (3 - len(old)); cs = list(coefs) + [0.0] * (4 - len(coefs))
+    for t in old:
+        _req(t, torch.float32, 'old')
+    a.old1, a.old2, a.old3 = _p(olds[0]), _p(olds[1]), _p(olds[2])
+    a.n, a.c, a.hw, a.uncond_first, a.mode = n, c, hw, 1, mode
+    a.guidance, a.c0, a.c1, a.c2, a.c3, a.div = guidance, cs[0], cs[1], cs[2], cs[3], div
+    if v_coef is not None:
+        a.v_pred, a.vc0, a.vc1 = 1, v_coef[0], v_coef[1]
+    a.sqrt_one_minus_at, a.sqrt_at, a.sqrt_a_prev, a.dir_coef = ddim['sqrt_one_minus_at'], ddim['sqrt_at'], ddim['sqrt_a_prev'], ddim['dir_coef']
+    if stage is not None:
+        x_dst, temb_row, temb_dst = stage
+        _req(x_dst, torch.float32, 'x_dst'); _req(temb_row, torch.float16, 'temb_row'); _req(temb_dst, torch.float16, 'temb_dst')
+        a.x_stage, a.stage_reps = _p(x_dst), x_dst.numel() // x.numel()
+        assert a.stage_reps * x.numel() == x_dst.numel() and temb_dst.numel() % temb_row.numel() == 0
+        a.temb_row, a.temb_dst, a.temb_width, a.temb_reps = _p(temb_row), _p(temb_dst), temb_row.numel(), temb_dst.numel() // temb_row.numel()
+    check(lib.sdod_plms_update(ctypes.byref(a), _stream()))
+    return e_out
+
+
 def stage_unet_inputs(x, x_dst, temb_row, temb_dst):
     """x fp32 [n,...] -> x_dst [reps*n,...] (repeated back to back); temb_row fp16 [w] -> every row of temb_dst [b, w]"""
     lib = _lib.hip()

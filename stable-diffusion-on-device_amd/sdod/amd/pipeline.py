@@ -151,20 +151,36 @@ class Txt2Img:
         self._set_context(ctx2)
         x = x_T.to(self.device, torch.float32).clone()
         old = []
+        staged = False   # the previous step's fused update already staged this evaluation's inputs
+        n_steps = len(sch.time_range)
         for i, step in enumerate(sch.time_range):
             index = sch.steps - i - 1
             vc = sch.v_to_eps_coef(index) if self.v_prediction else None
-            e_t = self._eps(x, temb[index], guidance, mode=1, v_coef=vc)
-            if len(old) == 0:
-                x_pred = x.clone()
-                ops.ddim_step(x_pred, e_t, **sch.coef(index))
-                nxt = max(index - 1, 0)
-                e_next = self._eps(x_pred, temb[nxt], guidance, mode=1, v_coef=sch.v_to_eps_coef(nxt) if self.v_prediction else None)
-                e_prime = ops.lincomb4([e_t, e_next], [1.0, 1.0], 2.0)
-            else:
+            if len(old) > 0:
+                # steps 2..: stage (unless done) -> UNet -> ONE launch for guidance, the multistep combination, the DDIM update
+                # and the staging of the next evaluation's inputs (ops.plms_update = the four separate launches, bit for bit)
+                if not staged:
+                    ops.stage_unet_inputs(x, self.unet.x, temb[index], self.unet.temb)
+                self.unet.execute(self.use_hip_graph, static_unchanged=not self._ctx_fresh)
+                self._ctx_fresh = False
+                eps = self._exchange_halves(self.unet.eps) if self.cfg_split else self.unet.eps
                 k = min(len(old), 3)
                 coefs, div = PLMS_ORDERS[k]
-                e_prime = ops.lincomb4([e_t] + old[::-1][:k], coefs, div)
+                nxt_stage = (self.unet.x, temb[index - 1], self.unet.temb) if i + 1 < n_steps else None
+                e_t = ops.plms_update(eps, x, old[::-1][:k], coefs, div, sch.coef(index), guidance, mode=1, v_coef=vc, stage=nxt_stage)
+                staged = nxt_stage is not None
+                old.append(e_t)
+                old = old[-3:]
+                if trace is not None:
+                    trace.append((int(step), index))
+                continue
+            # first step (pseudo improved Euler, two evaluations): the separate launches
+            e_t = self._eps(x, temb[index], guidance, mode=1, v_coef=vc)
+            x_pred = x.clone()
+            ops.ddim_step(x_pred, e_t, **sch.coef(index))
+            nxt = max(index - 1, 0)
+            e_next = self._eps(x_pred, temb[nxt], guidance, mode=1, v_coef=sch.v_to_eps_coef(nxt) if self.v_prediction else None)
+            e_prime = ops.lincomb4([e_t, e_next], [1.0, 1.0], 2.0)
             ops.ddim_step(x, e_prime, **sch.coef(index))
             old.append(e_t)
             old = old[-3:]

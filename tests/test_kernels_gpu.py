@@ -1056,3 +1056,35 @@ def test_latent_im2col_equals_latent_prep_then_im2col():
         x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(n * 100 + h)).cuda()
         ref = ops.im2col3x3_small(ops.nchw_f32_to_nhwc_f16(x, scale), 64)
         assert torch.equal(ops.latent_im2col(x, 64, scale), ref), (n, c, h, w)
+
+
+@pytest.mark.parametrize('k,v_pred,stage', [(1, False, True), (2, False, True), (3, False, False), (3, True, True)])
+def test_plms_update_equals_the_four_launches(k, v_pred, stage):
+    """sdod_plms_update (guidance + multistep combination + DDIM update + staging of the next evaluation's inputs in one launch)
+    against cfg_combine -> [v -> eps] -> lincomb4 -> ddim_step -> stage_unet_inputs, bit for bit"""
+    from sdod.amd import ops
+    from sdod.amd.samplers import PlmsSchedule, PLMS_ORDERS
+    g = torch.Generator().manual_seed(10 * k + v_pred)
+    n, c, h, w, tw = 2, 4, 16, 24, 96
+    eps = torch.randn(2 * n, h, w, c, generator=g).half().cuda()
+    x = torch.randn(n, c, h, w, generator=g).cuda()
+    old = [torch.randn(n, c, h, w, generator=g).cuda() for _ in range(k)]
+    temb_row = torch.randn(tw, generator=g).half().cuda()
+    sch = PlmsSchedule(20)
+    coefs, div = PLMS_ORDERS[k]
+    vc = sch.v_to_eps_coef(7) if v_pred else None
+    # reference: the separate launches
+    xr = x.clone()
+    e_t = ops.cfg_combine(eps, 7.5, uncond_first=True, mode=1)
+    if vc is not None:
+        e_t = ops.lincomb4([e_t, xr], [vc[0], vc[1]], 1.0)
+    ops.ddim_step(xr, ops.lincomb4([e_t] + old, coefs, div), **sch.coef(7))
+    xs_ref = torch.empty(2 * n, c, h, w, device='cuda'); ts_ref = torch.empty(2 * n, tw, dtype=torch.float16, device='cuda')
+    ops.stage_unet_inputs(xr, xs_ref, temb_row, ts_ref)
+    # fused
+    xf = x.clone()
+    xs = torch.zeros_like(xs_ref); ts = torch.zeros_like(ts_ref)
+    e_f = ops.plms_update(eps, xf, old, coefs, div, sch.coef(7), 7.5, mode=1, v_coef=vc, stage=(xs, temb_row, ts) if stage else None)
+    assert torch.equal(e_f, e_t) and torch.equal(xf, xr)
+    if stage:
+        assert torch.equal(xs, xs_ref) and torch.equal(ts, ts_ref)
