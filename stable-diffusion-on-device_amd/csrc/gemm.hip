@@ -2566,6 +2566,7 @@ size_t panel_smem(int bm, int bn, int K) {
 bool panel_ok(const sdod_gemm_desc* d, int tile) {
     if (!is_panel_tile(tile)) return false;
     if (d->a_mode != SDOD_A_ROWS || d->wq || d->k_tail || d->bias_on_m || d->row_bias || d->bias2 || d->split_k > 1) return false;
+    if (d->w_img_stride || d->vec_img_stride || d->softmax_cols) return false; // per-image operands / the softmax epilogue live in the ring kernel
     if (d->K % BK || d->K / BK < 3 || d->N % 8 || d->ldo % 8 || ((uintptr_t)d->out & 15) || (d->geglu && d->N % 32)) return false;
     if (d->residual && (d->geglu || d->ldr % 4 || ((uintptr_t)d->residual & 7))) return false;
     if ((unsigned long long)d->M * d->lda * 2 >= (1ull << 32) || (unsigned long long)d->N * d->ldw * 2 >= (1ull << 32)) return false;

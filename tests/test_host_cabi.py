@@ -273,6 +273,53 @@ def test_apanel_tile_eligibility_without_a_gpu():
     assert lib.sdod_gemm_tile_info(57, info) == 0 and list(info)[:6] == [128, 160, 2, 2, 3, 1]   # ring tiles for the softmax-epilogue GEMM
 
 
+def test_plan_of_the_folded_cross_attention_gemms_without_a_gpu():
+    """host side of sdod_gemm_desc::{softmax_cols, w_img_stride} (include/sdod_hip.h): the plan only ever names a ring tile whose
+    waves own 80 columns for the softmax epilogue, a tile whose rows divide the image for per-image weights, never split-K with
+    per-image vectors; the A-panel tiles refuse both (sdod_gemm_plan is host-only)"""
+    import ctypes
+    from sdod.amd import _lib
+    from sdod.amd._lib import GemmDesc
+    lib = _lib.hip()
+
+    def rows(m, n, k, **kw):
+        d = GemmDesc()
+        d.a = d.w = d.out = 0x1000
+        d.M, d.N, d.K, d.lda, d.ldw, d.ldo = m, n, k, k, k, n
+        for key, v in kw.items():
+            setattr(d, key, v)
+        return d
+
+    def plan(d):
+        t, s = ctypes.c_int(), ctypes.c_int()
+        assert lib.sdod_gemm_plan(ctypes.byref(d), ctypes.byref(t), ctypes.byref(s)) == 0
+        return t.value, s.value
+
+    wave80 = {21, 22, 31, 35, 48, 56, 57, 58, 59, 60}
+    info = (ctypes.c_int * 7)()
+    for t in wave80:                                            # "80 columns per wave" is a property of the tile table
+        assert lib.sdod_gemm_tile_info(t, info) == 0 and info[1] // info[3] == 80, t
+    score = dict(ln=1, softmax_cols=80, w_img_stride=640 * 320, vec_img_stride=640)
+    for tile in list(range(1, 61)):
+        t, s = plan(rows(8192, 640, 320, rows_per_img=4096, tile=tile, split_k=0, **score))
+        assert t in wave80 and s == 1, (tile, t, s)
+        assert lib.sdod_gemm_tile_info(t, info) == 0 and 4096 % info[0] == 0
+    # the 8x8 level: 64 rows per image -- a 128-row tile would straddle two weight matrices
+    for tile in (57, 23, 14, 9, 53):
+        t, s = plan(rows(128, 640, 1280, rows_per_img=64, tile=tile, split_k=0, **score))
+        assert t in wave80 and lib.sdod_gemm_tile_info(t, info) == 0 and 64 % info[0] == 0, (tile, t)
+    # second GEMM: per-image weights, shared bias -- any ring tile whose rows divide the image, split-K allowed
+    out = dict(w_img_stride=320 * 640)
+    t, s = plan(rows(8192, 320, 640, rows_per_img=4096, tile=31, split_k=0, **out))
+    assert t == 31
+    t, s = plan(rows(128, 1280, 640, rows_per_img=64, tile=23, split_k=2, **out))
+    assert lib.sdod_gemm_tile_info(t, info) == 0 and 64 % info[0] == 0 and info[5] == 1 and s == 2
+    t, s = plan(rows(8192, 320, 640, rows_per_img=4096, tile=53, split_k=0, **out))
+    assert lib.sdod_gemm_tile_info(t, info) == 0 and info[5] != 3     # not an A-panel tile
+    assert lib.sdod_gemm_panel_ok(ctypes.byref(rows(8192, 2560, 320, w_img_stride=2560 * 320, rows_per_img=4096)), 53) == 0
+    assert lib.sdod_gemm_panel_ok(ctypes.byref(rows(8192, 640, 320, softmax_cols=80)), 53) == 0
+
+
 def test_group_norm_workspace_layout_keeps_the_barrier_lines_out_of_reach():
     """one grow-only workspace serves every (n, groups); the grid barrier's counter lines sit at a FIXED offset in
     front, so the partial sums of no layout can land on the lines another layout uses"""
