@@ -492,7 +492,7 @@ const int kCandidates[] = {1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 17, 18, 1
                            46, 47, 48,
                            49, 50, 51, 52, // halo-patch tiles of 96 / 192 rows (image rows that are multiples of 3: config 5)
                            53, 54, 55,     // A-panel tiles (short-K wide-N Linears): rejected by every other descriptor
-                           56, 57, 58, 59, 60}; // ring tiles whose waves own a head's 80 columns: the softmax-epilogue GEMM of the folded cross-attention
+                           56, 57, 58, 59, 60, 61}; // ring tiles whose waves own a head's 80 columns: the softmax-epilogue GEMM of the folded cross-attention
 
 struct ShapeKey {
     static constexpr int kFields = 14;

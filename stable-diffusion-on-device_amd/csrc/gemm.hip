@@ -2495,9 +2495,12 @@ const TileCfg kTiles[] = {{0, 0},     {128, 128}, {128, 64}, {64, 64},   {256, 1
                           {32, 160}, {128, 160}, {64, 160},
                           // 59..60: ONE head (80 columns) per workgroup, 2 consumer + 2 loader waves: twice the workgroups of the 160-wide
                           // tiles for the row-starved score GEMMs (M = 512: 128 instead of 64) at 58 % of their bytes each
-                          {32, 80}, {64, 80}};
-constexpr int kNumTiles = 60;
-constexpr bool is_ring_tile(int t) { return (t >= 6 && t <= 36) || (t >= 46 && t <= 48) || (t >= 56 && t <= 60); } // gemm_glds_kernel
+                          {32, 80}, {64, 80},
+                          // 61: 128 x 160 with the four consumer waves stacked on the rows (32 x 160 each: an EVEN number of 16-column blocks,
+                          // so the GEGLU epilogue can pair value / gate): M = 512 x N = 10240 is exactly 256 workgroups
+                          {128, 160}};
+constexpr int kNumTiles = 61;
+constexpr bool is_ring_tile(int t) { return (t >= 6 && t <= 36) || (t >= 46 && t <= 48) || (t >= 56 && t <= 61); } // gemm_glds_kernel
 constexpr bool is_wave80_tile(int t) { return t == 21 || t == 22 || t == 31 || t == 35 || t == 48 || (t >= 56 && t <= 60); } // 80 columns per wave
 constexpr int kFirstPanelTile = 53, kLastPanelTile = 55;
 constexpr bool is_panel_tile(int t) { return t >= kFirstPanelTile && t <= kLastPanelTile; }
@@ -2879,7 +2882,7 @@ extern "C" int sdod_gemm_tile_info(int tile, int out[7]) {
         {96, 160, 2, 2, 3, 2, 1}, {96, 64, 2, 2, 4, 2, 1}, {192, 80, 4, 1, 4, 2, 1}, {192, 64, 4, 1, 4, 2, 1},
         // SPEC column 3 = gemm_apanel_kernel<BM, BN, WM, WN, STAGES>
         {128, 128, 2, 2, kPanelStages, 3, 1}, {64, 128, 2, 2, kPanelStages, 3, 1}, {32, 128, 2, 2, kPanelStages, 3, 1},
-        {32, 160, 2, 2, 6, 1, 1}, {128, 160, 2, 2, 3, 1, 1}, {64, 160, 2, 2, 2, 1, 1}, {32, 80, 2, 1, 5, 1, 1}, {64, 80, 2, 1, 5, 1, 1}};
+        {32, 160, 2, 2, 6, 1, 1}, {128, 160, 2, 2, 3, 1, 1}, {64, 160, 2, 2, 2, 1, 1}, {32, 80, 2, 1, 5, 1, 1}, {64, 80, 2, 1, 5, 1, 1}, {128, 160, 4, 1, 3, 1, 1}};
     static_assert(sizeof(kInfo) / sizeof(kInfo[0]) == kNumTiles + 1, "one row per tile");
     if (tile < 1 || tile > kNumTiles || !out) return sdod::INVALID_ARGUMENT;
     for (int i = 0; i < 7; ++i) out[i] = kInfo[tile][i];
@@ -3137,6 +3140,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     case 58: e = launch_glds<64, 160, 2, 2, 2, true>(p, grid, st); break;
     case 59: e = launch_glds<32, 80, 2, 1, 5, true>(p, grid, st); break;
     case 60: e = launch_glds<64, 80, 2, 1, 5, true>(p, grid, st); break;
+    case 61: e = launch_glds<128, 160, 4, 1, 3, true>(p, grid, st); break;
     default: e = launch_glds<128, 128, 2, 2, 2, true, false, 2>(p, grid, st); break;
     }
     SDOD_HIP_CHECK(e);

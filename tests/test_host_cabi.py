@@ -269,7 +269,7 @@ def test_apanel_tile_eligibility_without_a_gpu():
     assert lib.sdod_gemm_plan(ctypes.byref(d), ctypes.byref(t), ctypes.byref(s)) == 0 and (t.value, s.value) == (53, 1)
     info = (ctypes.c_int * 7)()
     assert lib.sdod_gemm_tile_info(54, info) == 0 and list(info)[:4] == [64, 128, 2, 2] and info[5] == 3
-    assert lib.sdod_gemm_num_tiles() == 60
+    assert lib.sdod_gemm_num_tiles() == 61
     assert lib.sdod_gemm_tile_info(57, info) == 0 and list(info)[:6] == [128, 160, 2, 2, 3, 1]   # ring tiles for the softmax-epilogue GEMM
 
 
@@ -300,7 +300,7 @@ def test_plan_of_the_folded_cross_attention_gemms_without_a_gpu():
     for t in wave80:                                            # "80 columns per wave" is a property of the tile table
         assert lib.sdod_gemm_tile_info(t, info) == 0 and info[1] // info[3] == 80, t
     score = dict(ln=1, softmax_cols=80, w_img_stride=640 * 320, vec_img_stride=640)
-    for tile in list(range(1, 61)):
+    for tile in list(range(1, lib.sdod_gemm_num_tiles() + 1)):
         t, s = plan(rows(8192, 640, 320, rows_per_img=4096, tile=tile, split_k=0, **score))
         assert t in wave80 and s == 1, (tile, t, s)
         assert lib.sdod_gemm_tile_info(t, info) == 0 and 4096 % info[0] == 0

@@ -207,7 +207,7 @@ def test_conv1x1_two_sources():
     check(out, ref, name='conv1x1 concat')
 
 
-@pytest.mark.parametrize('tile', [0, 6, 8, 10, 14, 16, 20, 21, 22, 23, 25, 26, 27, 29, 30, 31, 32, 34, 36, 46, 47, 48])
+@pytest.mark.parametrize('tile', [0, 6, 8, 10, 14, 16, 20, 21, 22, 23, 25, 26, 27, 29, 30, 31, 32, 34, 36, 46, 47, 48, 57, 59, 61])
 def test_gemm_fused_geglu(tile):
     """ff.net.0.proj + GEGLU in one launch: weight rows interleaved in 16-row [value | gate] blocks (tiles 21/22 cannot
     pair value and gate inside one wave: the planner must fall back, not skip the epilogue)"""
@@ -227,7 +227,7 @@ def test_gemm_fused_geglu(tile):
     check(out, ref, name=f'fused geglu tile{tile}')
 
 
-@pytest.mark.parametrize('tile', [0, 6, 8, 11, 14, 18, 20, 21, 22, 23, 25, 26, 27, 28, 30, 31, 32, 33, 35, 36, 46, 47, 48])
+@pytest.mark.parametrize('tile', [0, 6, 8, 11, 14, 18, 20, 21, 22, 23, 25, 26, 27, 28, 30, 31, 32, 33, 35, 36, 46, 47, 48, 56, 57, 58, 59, 60, 61])
 @pytest.mark.parametrize('m,c,n', [(600, 320, 960), (8192, 320, 320), (200, 1280, 1280)])
 def test_gemm_with_folded_layer_norm(tile, m, c, n):
     """LayerNorm -> Linear in one launch: row statistics gathered inside the GEMM, gamma folded into W"""
@@ -257,8 +257,9 @@ def test_gemm_ln_fold_with_geglu():
     perm[(j // 16) * 32 + j % 16] = j; perm[(j // 16) * 32 + 16 + j % 16] = H + j
     d = dev()
     wf, s, t = ops.ln_fold(w[perm].contiguous().to(d), gamma.to(d), beta.to(d), b[perm].contiguous().to(d))
-    out = ops.gemm(x.to(d), wf, t, ln_s=s, geglu=True)
-    check(out, ref, tol=3e-3, name='ln-fold + geglu')
+    for tile in (0, 14, 61):
+        out = ops.gemm(x.to(d), wf, t, ln_s=s, geglu=True, tile=tile)
+        check(out, ref, tol=3e-3, name=f'ln-fold + geglu tile{tile}')
 
 
 PANEL_TILES = {53: 320, 54: 640, 55: 1280}      # A-panel tiles and the K whose 80 KB row panel they are sized for

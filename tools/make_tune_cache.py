@@ -42,7 +42,7 @@ if only_quant or only_rows3 or only_ln or only_new or only_n160 or only_geglu or
             elif only_geglu:
                 drop = (int(v[10]) & 2) and (int(v[10]) & (1 << 30))
             elif only_n160:
-                drop = v[0] == '0' and int(v[2]) % 160 == 0 and not (int(v[10]) & (1 << 29))
+                drop = v[0] == '0' and int(v[2]) % 160 == 0 and not (int(v[10]) & ((1 << 29) | (1 << 28) | 2))   # (not uint8, not the score GEMMs, not GEGLU: those have their own switches)
             elif only_ln:
                 drop = int(v[10]) & (1 << 30)
             else:
@@ -79,7 +79,7 @@ if only_quant:
     print(f'done: {out}')
     sys.exit(0)
 
-if only_ln or only_n160 or only_geglu:
+if only_ln:
     c64 = E.sd14_config(64, 64)
     for b in (2, 4, 1):
         build(E.UNet, c64, b, 1234, f'sd14 unet 64x64 b{b}')
