@@ -245,21 +245,9 @@ __global__ __launch_bounds__(256 * KVS, (attn_min_waves<D, QT>())) void attn_ker
             if (c < 3) mx = fmaxf(fmaxf(mx, s_a[c][3]), s_a[c + 1][0]);
             else mx = fmaxf(mx, s_a[c][3]);
         }
-        // the four lanes that share a query (l, l ^ 16, l ^ 32, l ^ 48): gfx950's row swaps instead of two ds_bpermute round trips --
-        // v_permlane16_swap(x, x) = {rows 0 0 2 2 | rows 1 1 3 3}, v_permlane32_swap(x, x) = {rows 0 1 0 1 | rows 2 3 2 3}: the
-        // maximum of the two halves is the xor-16 / xor-32 reduction, in VALU latency, on the loop's critical path.
-        // (The results are copied out as integers first: __builtin_bit_cast applied to an ELEMENT of the builtin's vector result
-        // reads element 0 for every index with this compiler, which silently drops the maximum.)
-        {
-            const unsigned a16 = __builtin_bit_cast(unsigned, mx);
-            const auto s16 = __builtin_amdgcn_permlane16_swap(a16, a16, false, false);
-            const unsigned p0 = s16[0], p1 = s16[1];
-            mx = fmaxf(__builtin_bit_cast(float, p0), __builtin_bit_cast(float, p1));
-            const unsigned a32 = __builtin_bit_cast(unsigned, mx);
-            const auto s32 = __builtin_amdgcn_permlane32_swap(a32, a32, false, false);
-            const unsigned q0 = s32[0], q1 = s32[1];
-            mx = fmaxf(__builtin_bit_cast(float, q0), __builtin_bit_cast(float, q1));
-        }
+        // the four lanes that share a query: row swaps in VALU latency instead of two ds_bpermute round trips on the loop's
+        // critical path (common.h: quad_rows_max; profiles/r03_attention_permlane.txt)
+        mx = quad_rows_max(mx);
         const float m_new = fmaxf(m_run[a], mx * p.scale_log2); // running max in scaled (log2) units
         // once the running maxima have settled (a few tiles in) no lane of the wave changes its maximum: skip the
         // rescale of the output accumulators (wave-uniform branch)
@@ -428,9 +416,7 @@ __global__ __launch_bounds__(256 * KVS, (attn_min_waves<D, QT>())) void attn_ker
             // the row sum sits in output column D = (D / 16) * 16 + 4 g + r  ->  lane group g = (D % 16) / 4, register r = D % 4
             l = __shfl(o[a][D / 16][D % 4], ((D % 16) / 4) * 16 + li);
         } else {
-            l = l_run[a];
-            l += __shfl_xor(l, 16);
-            l += __shfl_xor(l, 32);
+            l = quad_rows_sum(l_run[a]);
         }
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         if (qrow[a] < p.Lq) {

@@ -21,6 +21,54 @@ SDOD_DEVICE f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+// Reductions over the four lanes l, l ^ 16, l ^ 32, l ^ 48 of a wave (the lanes that share a row in the MFMA accumulator layout)
+// with gfx950's row swaps instead of two ds_bpermute round trips: v_permlane16_swap(x, x) = {rows 0 0 2 2 | rows 1 1 3 3},
+// v_permlane32_swap(x, x) = {rows 0 1 0 1 | rows 2 3 2 3}; combining the two halves is the xor-16 / xor-32 step.
+// (The results are copied out as integers first: __builtin_bit_cast applied to an ELEMENT of the builtin's vector result reads
+// element 0 for every index with this compiler.)
+SDOD_DEVICE float quad_rows_max(float x) {
+    const unsigned a16 = __builtin_bit_cast(unsigned, x);
+    const auto s16 = __builtin_amdgcn_permlane16_swap(a16, a16, false, false);
+    const unsigned p0 = s16[0], p1 = s16[1];
+    x = fmaxf(__builtin_bit_cast(float, p0), __builtin_bit_cast(float, p1));
+    const unsigned a32 = __builtin_bit_cast(unsigned, x);
+    const auto s32 = __builtin_amdgcn_permlane32_swap(a32, a32, false, false);
+    const unsigned q0 = s32[0], q1 = s32[1];
+    return fmaxf(__builtin_bit_cast(float, q0), __builtin_bit_cast(float, q1));
+}
+SDOD_DEVICE float quad_rows_sum(float x) {
+    const unsigned a16 = __builtin_bit_cast(unsigned, x);
+    const auto s16 = __builtin_amdgcn_permlane16_swap(a16, a16, false, false);
+    const unsigned p0 = s16[0], p1 = s16[1];
+    x = __builtin_bit_cast(float, p0) + __builtin_bit_cast(float, p1);
+    const unsigned a32 = __builtin_bit_cast(unsigned, x);
+    const auto s32 = __builtin_amdgcn_permlane32_swap(a32, a32, false, false);
+    const unsigned q0 = s32[0], q1 = s32[1];
+    return __builtin_bit_cast(float, q0) + __builtin_bit_cast(float, q1);
+}
+
+// Sum / maximum over all 64 lanes, every lane gets the result: a butterfly of data-parallel-primitive moves inside the 16-lane rows
+// (quad permutes for the 1- and 2-lane steps, half-row and row mirrors for the 4- and 8-lane steps: a symmetric pairing is all a
+// reduction needs) and the two row swaps above, instead of six ds_bpermute round trips (~100 cycles each on a dependent chain).
+template <int CTRL>
+SDOD_DEVICE float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+SDOD_DEVICE float wave_sum(float v) {
+    v += dpp_move<0xB1>(v);  // quad_perm [1, 0, 3, 2]
+    v += dpp_move<0x4E>(v);  // quad_perm [2, 3, 0, 1]
+    v += dpp_move<0x141>(v); // row_half_mirror
+    v += dpp_move<0x140>(v); // row_mirror
+    return quad_rows_sum(v);
+}
+SDOD_DEVICE float wave_max(float v) {
+    v = fmaxf(v, dpp_move<0xB1>(v));
+    v = fmaxf(v, dpp_move<0x4E>(v));
+    v = fmaxf(v, dpp_move<0x141>(v));
+    v = fmaxf(v, dpp_move<0x140>(v));
+    return quad_rows_max(v);
+}
+
 SDOD_DEVICE f16x8 zero8() {
     f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     return z;

@@ -214,8 +214,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* x, f16* y,
             for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)v[i][e]);
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max(mx);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -232,8 +231,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* x, f16* y,
             }
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_sum(sum);
     if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = sum;
     __syncthreads();
     const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);

@@ -1292,7 +1292,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
         if constexpr (WTN == 80 && !WQ) {
             // Row softmax over the wave's 80 columns (the folded cross-attention: one head's 77 keys + 3 padding columns whose
             // bias is -30000, scores already in log2 units): a row's columns sit in this lane (TN blocks x 4) and in the three
-            // lanes 16 / 32 / 48 away -- two xor-shuffles per reduction, nothing leaves the wave.
+            // lanes 16 / 32 / 48 away -- two row swaps per reduction (quad_rows_max / _sum), nothing leaves the wave.
             if (p.softmax_g) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -1301,8 +1301,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                     for (int j = 0; j < TN; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r]);
-                    mx = fmaxf(mx, __shfl_xor(mx, 16));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    mx = quad_rows_max(mx);
                     float sum = 0.f;
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
@@ -1312,8 +1311,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                             acc[i][j][r] = e;
                             sum += e;
                         }
-                    sum += __shfl_xor(sum, 16);
-                    sum += __shfl_xor(sum, 32);
+                    sum = quad_rows_sum(sum);
                     const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
                     for (int j = 0; j < TN; ++j)

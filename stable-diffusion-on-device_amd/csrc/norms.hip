@@ -154,11 +154,8 @@ __global__ __launch_bounds__(256) void gn_collapse_kernel(const float* partial, 
         a += src[0];
         b += src[1];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        a += __shfl_xor(a, o);
-        b += __shfl_xor(b, o);
-    }
+    a = wave_sum(a);
+    b = wave_sum(b);
     if (lane == 0) {
         collapsed[((size_t)n * G + g) * 2 + 0] = a;
         collapsed[((size_t)n * G + g) * 2 + 1] = b;
@@ -184,11 +181,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnP p) {
                 a += src[0];
                 b += src[1];
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                a += __shfl_xor(a, o);
-                b += __shfl_xor(b, o);
-            }
+            a = wave_sum(a);
+            b = wave_sum(b);
             if (lane == 0) {
                 const float cnt = (float)p.HW * (float)p.Cg;
                 const float shift = p.shift[(size_t)n * p.G + g];
@@ -288,11 +282,8 @@ __global__ __launch_bounds__(NT) void gn_small_kernel(const GnP p, int sw) {
     }
 #pragma unroll
     for (int gi = 0; gi < 4; ++gi) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            s1[gi] += __shfl_xor(s1[gi], o);
-            s2[gi] += __shfl_xor(s2[gi], o);
-        }
+        s1[gi] = wave_sum(s1[gi]);
+        s2[gi] = wave_sum(s2[gi]);
         if (lane == 0) {
             red[(wave * 4 + gi) * 2 + 0] = s1[gi];
             red[(wave * 4 + gi) * 2 + 1] = s2[gi];
@@ -406,8 +397,7 @@ SDOD_DEVICE void pin(VT& v) {
 
 template <int NT>
 SDOD_DEVICE float block_sum(float v, float* red, int tid) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = wave_sum(v);
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
     float t = 0.f;
@@ -1291,11 +1281,8 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(f16* w, int N, int K, int 
         row[k] = folded;
         sacc += (float)folded;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        t += __shfl_xor(t, o);
-        sacc += __shfl_xor(sacc, o);
-    }
+    t = wave_sum(t);
+    sacc = wave_sum(sacc);
     if ((threadIdx.x & 63) == 0) {
         red[threadIdx.x >> 6] = t;
         red[4 + (threadIdx.x >> 6)] = sacc;
@@ -1411,8 +1398,7 @@ template <> struct NchwIo<bf16_tag> {
 };
 
 SDOD_DEVICE float block_sum_512(float v, float* red) { // red: >= 8 floats of LDS; every thread gets the total
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
