@@ -61,6 +61,33 @@ SDOD_DEVICE float wave_sum(float v) {
     v += dpp_move<0x140>(v); // row_mirror
     return quad_rows_sum(v);
 }
+SDOD_DEVICE float oct_sum(float v) { // sum over the aligned group of 8 lanes a lane belongs to, in every lane of the group
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    return v;
+}
+template <int N>
+SDOD_DEVICE float group_sum(float v) { // sum over the aligned group of N = 2 .. 64 lanes a lane belongs to, in every lane of the group
+    static_assert(N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 64, "power of two");
+    v += dpp_move<0xB1>(v);
+    if constexpr (N >= 4) v += dpp_move<0x4E>(v);
+    if constexpr (N >= 8) v += dpp_move<0x141>(v);
+    if constexpr (N >= 16) v += dpp_move<0x140>(v);
+    if constexpr (N >= 32) {
+        const unsigned a16 = __builtin_bit_cast(unsigned, v);
+        const auto s16 = __builtin_amdgcn_permlane16_swap(a16, a16, false, false);
+        const unsigned p0 = s16[0], p1 = s16[1];
+        v = __builtin_bit_cast(float, p0) + __builtin_bit_cast(float, p1);
+    }
+    if constexpr (N >= 64) {
+        const unsigned a32 = __builtin_bit_cast(unsigned, v);
+        const auto s32 = __builtin_amdgcn_permlane32_swap(a32, a32, false, false);
+        const unsigned q0 = s32[0], q1 = s32[1];
+        v = __builtin_bit_cast(float, q0) + __builtin_bit_cast(float, q1);
+    }
+    return v;
+}
 SDOD_DEVICE float wave_max(float v) {
     v = fmaxf(v, dpp_move<0xB1>(v));
     v = fmaxf(v, dpp_move<0x4E>(v));

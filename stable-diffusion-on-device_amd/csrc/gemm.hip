@@ -765,11 +765,8 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             float a1 = rs1[i], a2 = rs2[i];
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
-                a1 += __shfl_xor(a1, o);
-                a2 += __shfl_xor(a2, o);
-            }
+            a1 = oct_sum(a1); // (the eight lanes of a row's 128-byte slab line: DPP moves, no ds_bpermute on the kernel's tail)
+            a2 = oct_sum(a2);
             if ((lane & 7) == 0) {
                 const float mean = a1 / (float)p.K;
                 float var = a2 / (float)p.K - mean * mean;
@@ -1478,11 +1475,8 @@ __global__ __launch_bounds__(768) void gemm_apanel_kernel(const GemmP p, const f
 #pragma unroll
                 for (int i = 0; i < A_LD; ++i) {
                     float a1 = rs1[i], a2 = rs2[i];
-#pragma unroll
-                    for (int o = 1; o < 8; o <<= 1) {
-                        a1 += __shfl_xor(a1, o);
-                        a2 += __shfl_xor(a2, o);
-                    }
+                    a1 = oct_sum(a1);
+                    a2 = oct_sum(a2);
                     if ((lane & 7) == 0) {
                         const float mean = a1 / (float)p.K;
                         float var = a2 / (float)p.K - mean * mean;

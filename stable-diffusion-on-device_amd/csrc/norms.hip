@@ -723,11 +723,8 @@ __global__ __launch_bounds__(256) void gn2_apply_kernel(const Gn2P p) {
             a += src[0];
             b += src[1];
         }
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-            a += __shfl_xor(a, o);
-            b += __shfl_xor(b, o);
-        }
+        a = oct_sum(a);
+        b = oct_sum(b);
         if (l == 0) {
             const float cnt = (float)p.HW * (float)p.Cg;
             const float md = a / cnt;
@@ -977,11 +974,8 @@ __global__ __launch_bounds__(512) void gn_grid_kernel(const GnGridP p) {
                 b += pr.y;
             }
         }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            a += __shfl_xor(a, o);
-            b += __shfl_xor(b, o);
-        }
+        a = group_sum<16>(a);
+        b = group_sum<16>(b);
         if (g < p.G && l == 0) {
             const float cnt = (float)p.HW * (float)p.Cg;
             const float md = a / cnt;
@@ -1231,8 +1225,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const f16* x, f16* y, c
         for (int k = 0; k < KC; ++k)
 #pragma unroll
             for (int e = 0; e < 8; ++e) sum += (float)v[k][e];
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        sum = group_sum<LPR>(sum);
         const float mean = sum * inv_c;
         float sq = 0.f;
 #pragma unroll
@@ -1245,8 +1238,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const f16* x, f16* y, c
                 }
             }
         }
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        sq = group_sum<LPR>(sq);
         const float rstd = 1.0f / sqrtf(sq * inv_c + eps);
         f16* yr = y + (size_t)(ok ? row : 0) * C;
 #pragma unroll
