@@ -236,14 +236,18 @@ __global__ __launch_bounds__(256 * KVS, (attn_min_waves<D, QT>())) void attn_ker
                     s_a[c][r] = masked ? -1e30f : s_a[c][r];
                 }
         }
-        // row maximum of this lane's 16 scores as a chain of three-input maxima (v_max3_f32: 8 instructions instead of 15)
-        float mx = fmaxf(fmaxf(s_a[0][0], s_a[0][1]), s_a[0][2]);
-        mx = fmaxf(fmaxf(mx, s_a[0][3]), s_a[1][0]);
-#pragma unroll
-        for (int c = 1; c < 4; ++c) {
-            mx = fmaxf(fmaxf(mx, s_a[c][1]), s_a[c][2]);
-            if (c < 3) mx = fmaxf(fmaxf(mx, s_a[c][3]), s_a[c + 1][0]);
-            else mx = fmaxf(mx, s_a[c][3]);
+        // row maximum of this lane's 16 scores: three-input maxima (v_max3_f32: 8 instructions instead of 15) as a TREE of depth 3,
+        // not a chain of 8 -- the maximum heads the tile's dependent chain (max -> exp -> PV)
+        float mx;
+        {
+            const float t0 = fmaxf(fmaxf(s_a[0][0], s_a[0][1]), s_a[0][2]);
+            const float t1 = fmaxf(fmaxf(s_a[0][3], s_a[1][0]), s_a[1][1]);
+            const float t2 = fmaxf(fmaxf(s_a[1][2], s_a[1][3]), s_a[2][0]);
+            const float t3 = fmaxf(fmaxf(s_a[2][1], s_a[2][2]), s_a[2][3]);
+            const float t4 = fmaxf(fmaxf(s_a[3][0], s_a[3][1]), s_a[3][2]);
+            const float u0 = fmaxf(fmaxf(t0, t1), t2);
+            const float u1 = fmaxf(fmaxf(t3, t4), s_a[3][3]);
+            mx = fmaxf(u0, u1);
         }
         // the four lanes that share a query: row swaps in VALU latency instead of two ds_bpermute round trips on the loop's
         // critical path (common.h: quad_rows_max; profiles/r03_attention_permlane.txt)
