@@ -319,6 +319,22 @@ typedef struct sdod_plms_update_args {
     float guidance, vc0, vc1, c0, c1, c2, c3, div, sqrt_one_minus_at, sqrt_at, sqrt_a_prev, dir_coef;
 } sdod_plms_update_args;
 SDOD_API int sdod_plms_update(const sdod_plms_update_args* a, void* stream);
+
+/* The reference driver's per-step arithmetic behind a UNet evaluation in one launch (src/context.cpp:359-373: CFG; src/dpm_solver.cpp:
+ * 139-180: DPM-Solver++(2M) update; :348-352: staging of the next step's inputs): sdod_cfg_combine + sdod_dpm_update +
+ * sdod_stage_unet_inputs, the same fp32 operations in the same order, bit for bit.  e_out, x_stage, temb_row may be NULL. */
+typedef struct sdod_dpm_step_args {
+    const void* eps_nhwc;   /* fp16 [2n][hw][c] */
+    float* e_out;           /* fp32 [n][c][hw] or NULL */
+    float* x;               /* fp32 [n][c][hw], updated in place */
+    float* y_prev;          /* fp32 [n][c][hw], read (order 2) and replaced */
+    float* x_stage;         /* fp32 [stage_reps][n][c][hw] or NULL */
+    const void* temb_row;   /* fp16 [temb_width] or NULL */
+    void* temb_dst;         /* fp16 [temb_reps][temb_width] */
+    int n, c, hw, uncond_first, mode, order, stage_reps, temb_width, temb_reps;
+    float guidance, sigma_s, alpha_s, sigma_ratio, c_prev, c_cur;
+} sdod_dpm_step_args;
+SDOD_API int sdod_dpm_step(const sdod_dpm_step_args* a, void* stream);
 /* img: fp16 NHWC [n][hw][3] -> uint8 HWC per image, f = a*v+b, truncating cast:
  *   mode 0: clamp(255*f, 0, 255)   (context.cpp:392-395; a=1,b=0 is the reference's already-[0,1] convention)
  *   mode 1: 255*clamp(f, 0, 1)     (ldm txt2img with a=0.5, b=0.5) */

@@ -370,6 +370,46 @@ __global__ void plms_update_kernel(const sdod_plms_update_args a) {
     }
 }
 
+// The reference driver's per-step arithmetic behind a UNet evaluation in ONE launch (context.cpp:359-373 + dpm_solver.cpp:139-180 +
+// the next step's input staging, :348-352): cfg_kernel (either mode), dpm_update_kernel and stage_unet_inputs_kernel, the same
+// fp32 operations in the same order -- bit-identical to the three launches (test_dpm_step_equals_the_three_launches).
+__global__ void dpm_step_kernel(const sdod_dpm_step_args a) {
+    const size_t lat = (size_t)a.n * a.c * a.hw;
+    const size_t nt = a.temb_row ? (size_t)a.temb_width * a.temb_reps : 0;
+    const f16* eps = (const f16*)a.eps_nhwc;
+    GRID_STRIDE(i, lat + nt) {
+        if (i >= lat) {
+            ((f16*)a.temb_dst)[i - lat] = ((const f16*)a.temb_row)[(i - lat) % a.temb_width];
+            continue;
+        }
+        const int pix = (int)(i % a.hw);
+        const size_t t = i / a.hw;
+        const int ch = (int)(t % a.c);
+        const int img = (int)(t / a.c);
+        const int iu = a.uncond_first ? img : img + a.n;
+        const int ic = a.uncond_first ? img + a.n : img;
+        const float eu = (float)eps[((size_t)iu * a.hw + pix) * a.c + ch];
+        const float ec = (float)eps[((size_t)ic * a.hw + pix) * a.c + ch];
+        float e;
+        if (a.mode == 0) {
+            e = mul_rn(ec, a.guidance);
+            e = add_rn(e, mul_rn(eu, sub_rn(1.0f, a.guidance)));
+        } else {
+            e = add_rn(eu, mul_rn(a.guidance, sub_rn(ec, eu)));
+        }
+        if (a.e_out) a.e_out[i] = e;
+        const float xv = a.x[i];
+        const float y = div_rn(add_rn(xv, mul_rn(-a.sigma_s, e)), a.alpha_s);
+        float xn = mul_rn(xv, a.sigma_ratio);
+        if (a.order == 2) xn = add_rn(xn, mul_rn(a.c_prev, a.y_prev[i]));
+        xn = add_rn(xn, mul_rn(a.c_cur, y));
+        a.x[i] = xn;
+        a.y_prev[i] = y;
+        if (a.x_stage)
+            for (int r = 0; r < a.stage_reps; ++r) a.x_stage[(size_t)r * lat + i] = xn;
+    }
+}
+
 __global__ void stage_unet_inputs_kernel(const float* x, float* x_dst, size_t lat, int reps, const f16* temb_row, f16* temb_dst,
                                          size_t temb_w, int temb_reps) {
     const size_t nx = lat * (size_t)reps, nt = temb_w * (size_t)temb_reps;
@@ -545,6 +585,18 @@ extern "C" int sdod_plms_update(const sdod_plms_update_args* a, void* stream) {
     SDOD_REQUIRE(!a->temb_row || (a->temb_dst && a->temb_width > 0 && a->temb_reps > 0), "bad time-conditioning argument");
     const size_t work = (size_t)a->n * a->c * a->hw + (a->temb_row ? (size_t)a->temb_width * a->temb_reps : 0);
     LAUNCH(plms_update_kernel, work, stream, *a);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_dpm_step(const sdod_dpm_step_args* a, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(a && a->eps_nhwc && a->x && a->y_prev && a->n > 0 && a->c > 0 && a->hw > 0 && (a->mode == 0 || a->mode == 1) &&
+                     (a->order == 1 || a->order == 2), "bad argument");
+    SDOD_REQUIRE(!a->x_stage || a->stage_reps > 0, "x_stage needs stage_reps");
+    SDOD_REQUIRE(!a->temb_row || (a->temb_dst && a->temb_width > 0 && a->temb_reps > 0), "bad time-conditioning argument");
+    const size_t work = (size_t)a->n * a->c * a->hw + (a->temb_row ? (size_t)a->temb_width * a->temb_reps : 0);
+    LAUNCH(dpm_step_kernel, work, stream, *a);
     return 0;
     SDOD_CATCH
 }

@@ -176,15 +176,25 @@ void Context::generate(const std::string& prompt, float guidance, unsigned char*
     injected_ = false;
     SDOD_HIP_CHECK(hipMemcpyAsync(x_dev_, x_host_.data(), lat * sizeof(float), hipMemcpyHostToDevice, stream_));
 
+    // both batch rows see the same latent and time embedding (context.cpp:348-352, :364-366): one staging launch for the first
+    // step; from then on the step's own launch stages the next one
+    rc_check(sdod_stage_unet_inputs(x_dev_, static_cast<float*>(ux.ptr), lat, 2, temb_cache_, ut.ptr, temb_row / sizeof(f16), 2, stream_));
     for (unsigned step = 0; step < steps_; ++step) {
-        // both batch rows see the same latent and time embedding (context.cpp:348-352, :364-366): one staging launch
-        const char* te = reinterpret_cast<const char*>(temb_cache_) + step * temb_row;
-        rc_check(sdod_stage_unet_inputs(x_dev_, static_cast<float*>(ux.ptr), lat, 2, te, ut.ptr, temb_row / sizeof(f16), 2, stream_));
         unet_->execute(stream_, true, /*skip_static=*/step > 0); // the text context only changes between images
-        // e = g*e_cond + (1-g)*e_uncond (context.cpp:359-373); g == 1 keeps e_cond only
-        rc_check(sdod_cfg_combine(ue.ptr, e_dev_, 1, C, HW, guidance, /*uncond_first=*/0, /*mode=*/0, stream_));
+        // ONE launch: e = g*e_cond + (1-g)*e_uncond (context.cpp:359-373; g == 1 keeps e_cond only), the DPM-Solver++(2M) update
+        // (dpm_solver.cpp:139-180) and the staging of the next step's inputs -- sdod_cfg_combine + sdod_dpm_update +
+        // sdod_stage_unet_inputs, bit for bit
         const DpmSolver::StepCoef k = solver_->coef(step);
-        rc_check(sdod_dpm_update(x_dev_, e_dev_, y_prev_, lat, k.order, k.sigma_s, k.alpha_s, k.sigma_ratio, k.c_prev, k.c_cur, stream_));
+        sdod_dpm_step_args a{};
+        a.eps_nhwc = ue.ptr; a.e_out = e_dev_; a.x = x_dev_; a.y_prev = y_prev_;
+        a.n = 1; a.c = C; a.hw = HW; a.uncond_first = 0; a.mode = 0; a.order = k.order;
+        a.guidance = guidance; a.sigma_s = k.sigma_s; a.alpha_s = k.alpha_s; a.sigma_ratio = k.sigma_ratio; a.c_prev = k.c_prev; a.c_cur = k.c_cur;
+        if (step + 1 < steps_) {
+            a.x_stage = static_cast<float*>(ux.ptr); a.stage_reps = 2;
+            a.temb_row = reinterpret_cast<const char*>(temb_cache_) + (size_t)(step + 1) * temb_row;
+            a.temb_dst = ut.ptr; a.temb_width = (int)(temb_row / sizeof(f16)); a.temb_reps = 2;
+        }
+        rc_check(sdod_dpm_step(&a, stream_));
         mark(2 + step);
     }
 

@@ -437,6 +437,29 @@ def plms_update(eps_nhwc, x, old, coefs, div, ddim, guidance, mode=1, v_coef=Non
     return e_out
 
 
+def dpm_step(eps_nhwc, x, y_prev, coef, guidance, mode=0, uncond_first=True, stage=None):
+    """the reference driver's per-step arithmetic in one launch (include/sdod_hip.h: sdod_dpm_step): CFG of eps, the
+    DPM-Solver++(2M) update of x / y_prev in place with coef = DpmSolver.coef(step), and -- with stage = (x_dst, temb_row,
+    temb_dst) -- the next evaluation's inputs"""
+    lib = _lib.hip()
+    _req(eps_nhwc, torch.float16, 'eps'); _req(x, torch.float32, 'x'); _req(y_prev, torch.float32, 'y_prev')
+    n2, c = eps_nhwc.shape[0], eps_nhwc.shape[-1]
+    n = n2 // 2
+    hw = eps_nhwc.numel() // (n2 * c)
+    assert x.numel() == n * c * hw == y_prev.numel()
+    a = _lib.DpmStepArgs()
+    a.eps_nhwc, a.x, a.y_prev = _p(eps_nhwc), _p(x), _p(y_prev)
+    a.n, a.c, a.hw, a.uncond_first, a.mode, a.order = n, c, hw, 1 if uncond_first else 0, mode, coef['order']
+    a.guidance = guidance
+    a.sigma_s, a.alpha_s, a.sigma_ratio, a.c_prev, a.c_cur = coef['sigma_s'], coef['alpha_s'], coef['sigma_ratio'], coef['c_prev'], coef['c_cur']
+    if stage is not None:
+        x_dst, temb_row, temb_dst = stage
+        _req(x_dst, torch.float32, 'x_dst'); _req(temb_row, torch.float16, 'temb_row'); _req(temb_dst, torch.float16, 'temb_dst')
+        a.x_stage, a.stage_reps = _p(x_dst), x_dst.numel() // x.numel()
+        a.temb_row, a.temb_dst, a.temb_width, a.temb_reps = _p(temb_row), _p(temb_dst), temb_row.numel(), temb_dst.numel() // temb_row.numel()
+    check(lib.sdod_dpm_step(ctypes.byref(a), _stream()))
+
+
 def stage_unet_inputs(x, x_dst, temb_row, temb_dst):
     """x fp32 [n,...] -> x_dst [reps*n,...] (repeated back to back); temb_row fp16 [w] -> every row of temb_dst [b, w]"""
     lib = _lib.hip()

@@ -196,9 +196,15 @@ class Txt2Img:
         self._set_context(ctx2)
         x = x_T.to(self.device, torch.float32).clone()
         y_prev = torch.zeros_like(x)
+        # one staging launch in front of the loop; every step is then the UNet replay + ONE launch (guidance, solver update and the
+        # staging of the next step's inputs: ops.dpm_step = cfg_combine + dpm_update + stage_unet_inputs, bit for bit)
+        ops.stage_unet_inputs(x, self.unet.x, temb[0], self.unet.temb)
         for s in range(steps):
-            e = self._eps(x, temb[s], guidance, mode=0)
-            ops.dpm_update(x, e, y_prev, **solver.coef(s))
+            self.unet.execute(self.use_hip_graph, static_unchanged=not self._ctx_fresh)
+            self._ctx_fresh = False
+            eps = self._exchange_halves(self.unet.eps) if self.cfg_split else self.unet.eps
+            ops.dpm_step(eps, x, y_prev, solver.coef(s), guidance, mode=0,
+                         stage=(self.unet.x, temb[s + 1], self.unet.temb) if s + 1 < steps else None)
         return x
 
     # ------------------------------------------------------------------ decode

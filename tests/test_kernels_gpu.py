@@ -1089,3 +1089,27 @@ def test_plms_update_equals_the_four_launches(k, v_pred, stage):
     assert torch.equal(e_f, e_t) and torch.equal(xf, xr)
     if stage:
         assert torch.equal(xs, xs_ref) and torch.equal(ts, ts_ref)
+
+
+@pytest.mark.parametrize('order,stage,uncond_first', [(1, True, True), (2, True, False), (2, False, True)])
+def test_dpm_step_equals_the_three_launches(order, stage, uncond_first):
+    """sdod_dpm_step (the reference driver's per-step arithmetic in one launch: context.cpp:359-373 guidance, dpm_solver.cpp:139-180
+    update, :348-352 staging) against cfg_combine -> dpm_update -> stage_unet_inputs, bit for bit"""
+    from sdod.amd import ops
+    g = torch.Generator().manual_seed(40 + order)
+    n, c, h, w, tw = 1, 4, 16, 24, 96
+    eps = torch.randn(2 * n, h, w, c, generator=g).half().cuda()
+    x = torch.randn(n, c, h, w, generator=g).cuda(); y = torch.randn(n, c, h, w, generator=g).cuda()
+    temb_row = torch.randn(tw, generator=g).half().cuda()
+    coef = dict(order=order, sigma_s=0.73, alpha_s=0.68, sigma_ratio=0.91, c_prev=-0.12, c_cur=0.31)
+    xr, yr = x.clone(), y.clone()
+    e = ops.cfg_combine(eps, 7.5, uncond_first=uncond_first, mode=0)
+    ops.dpm_update(xr, e, yr, **coef)
+    xs_ref = torch.empty(2 * n, c, h, w, device='cuda'); ts_ref = torch.empty(2 * n, tw, dtype=torch.float16, device='cuda')
+    ops.stage_unet_inputs(xr, xs_ref, temb_row, ts_ref)
+    xf, yf = x.clone(), y.clone()
+    xs = torch.zeros_like(xs_ref); ts = torch.zeros_like(ts_ref)
+    ops.dpm_step(eps, xf, yf, coef, 7.5, mode=0, uncond_first=uncond_first, stage=(xs, temb_row, ts) if stage else None)
+    assert torch.equal(xf, xr) and torch.equal(yf, yr)
+    if stage:
+        assert torch.equal(xs, xs_ref) and torch.equal(ts, ts_ref)
