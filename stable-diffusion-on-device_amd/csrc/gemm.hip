@@ -86,6 +86,7 @@ struct GemmP {
     int h_patch_halves;      // LDS halves of one patch buffer
     int h_colv_off;          // byte offset of the per-column epilogue vectors in LDS
     int h_main_splits;       // splits that walk the 3x3 taps (split h_main_splits, when k_tail != 0, walks the 1x1 tail)
+    int h_chain;             // 1: ONE split; its workgroups run the 1x1 tail behind the tap walk themselves (no partial slabs)
     unsigned mg_tw, sh_tw, mg_th, sh_th, mg_pw, sh_pw, mg_pp, sh_pp;
     // XCD-aware tile order (tile_of): the n-tiles are cut into xg panels, the first xg_r of them one tile wider (xg_w + 1);
     // logical ids walk panel after panel, m-major inside a panel.  xg = 1 is the plain m-major order.
@@ -1776,6 +1777,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
         kt_end = min(ktm, kt_begin + p.kt_per_split);
     }
     const int nkt = kt_end - kt_begin;
+    // CHAINED tail (h_chain: an unsplit convolution with a fused 1x1 skip): the workgroup walks the 3x3 taps and then, behind one
+    // workgroup barrier, runs the tail program itself on the same accumulators -- no partial slabs, no reduce launch
+    const bool chain = p.h_chain != 0 && !tail_wg;
+    const int nkt_t = (p.K - p.k_tail) / BK; // slabs of the 1x1 tail
 
     const int lrow = lane >> 3;
     const int lchunk = (lane & 7) ^ lrow;
@@ -1961,7 +1966,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
                     else wait_vmcnt<(AHEAD - 1 - t) * CNT>();
                     if (!(dbg & 128)) __builtin_amdgcn_s_barrier();
                 });
-            } else {
+            }
+            if (tail_wg || chain) {
+                if (chain) { // every slab and patch of the tap walk has landed and been read: the ring becomes the tail's
+                    wait_vmcnt<0>();
+                    __syncthreads();
+                }
                 // 1x1 tail: plain [BM][64] A slabs (the centre pixel of each output row) next to the weight slab
                 constexpr int SLOT = (BM + BN) * 64;
                 int a_pix[A_LD];
@@ -1989,12 +1999,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
                 };
 #pragma unroll
                 for (int s = 0; s < TAHEAD; ++s)
-                    if (s < nkt) issue(s, s);
-                STAMP(1);
-                for (int it = 0; it < nkt; ++it) {
-                    wait_younger<A_LD + CNT, TST - 2>(max(0, nkt - it - 1));
+                    if (s < nkt_t) issue(s, s);
+                if (!chain) STAMP(1);
+                for (int it = 0; it < nkt_t; ++it) {
+                    wait_younger<A_LD + CNT, TST - 2>(max(0, nkt_t - it - 1));
                     __builtin_amdgcn_s_barrier();
-                    if (it + TAHEAD < nkt) issue(it + TAHEAD, (it + TAHEAD) % TST);
+                    if (it + TAHEAD < nkt_t) issue(it + TAHEAD, (it + TAHEAD) % TST);
                 }
             }
         };
@@ -2171,11 +2181,16 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
-    } else {
+    }
+    if (tail_wg || chain) {
+        if (chain) {
+            __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): my last fragment reads are done
+            __syncthreads();
+        }
         // 1x1 tail slice: plain ring program
         constexpr int SLOT = (BM + BN) * 64;
-        STAMP(1);
-        for (int it = 0; it < nkt; ++it) {
+        if (!chain) STAMP(1);
+        for (int it = 0; it < nkt_t; ++it) {
             __builtin_amdgcn_s_barrier();
             const f16* sA = smem + (it % TST) * SLOT;
             const f16* sB = sA + BM * 64;
@@ -2625,6 +2640,7 @@ struct Plan {
     int splits;
     int kt_per_split;
     int main_splits; // halo tiles: splits over the 3x3 taps (a fused 1x1 tail is one more)
+    bool chain = false; // halo tiles, unsplit with a fused 1x1 tail: the tail runs behind the tap walk in the same workgroups
 };
 
 // Can halo tile `tile` run descriptor d?  Fills the geometry fields of *p (may be null) and the LDS bytes of the launch.
@@ -2784,6 +2800,14 @@ Plan make_plan(const sdod_gemm_desc* d) {
         pl.main_splits = (nmain + cps - 1) / cps;
         pl.kt_per_split = 9 * cps;
         pl.splits = pl.main_splits + (d->k_tail ? 1 : 0);
+        // an EXPLICIT split_k = 1 on a convolution with a fused 1x1 skip: no split at all -- the workgroups chain the tail behind
+        // the tap walk (conv_halo_kernel: h_chain).  uint8 weights keep the two-slice form (the tail has its own encoding).
+        if (d->k_tail && d->split_k == 1 && !d->wq) {
+            pl.main_splits = 1;
+            pl.kt_per_split = 9 * nmain;
+            pl.splits = 1;
+            pl.chain = true;
+        }
         return pl;
     }
     if (splits > KT) splits = KT;
@@ -3011,6 +3035,7 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     if (is_halo_tile(pl.tile)) {
         SDOD_REQUIRE(halo_geometry(d, pl.tile, &p, &halo_smem), "this halo-patch tile does not take the convolution (3x3, stride 1, tile rows must divide the image)");
         p.h_main_splits = pl.main_splits;
+        p.h_chain = pl.chain ? 1 : 0;
         if (fixup_applies(d, pl)) {
             p.fixup = 1;
             p.fix_counters = (unsigned*)d->fix_counters;

@@ -23,11 +23,12 @@ only_ln = '--only-ln' in sys.argv         # keep every shipped pick but those of
 only_n160 = '--only-n160' in sys.argv     # re-time the fp16 rows-mode shapes whose N is a multiple of 160 (candidates for the 160-wide tiles 56..58)
 only_geglu = '--only-geglu' in sys.argv   # re-time the LayerNorm-folded GEGLU projections (key flags: bit 1 and bit 30)
 only_softmax = '--only-softmax' in sys.argv # re-time the score GEMMs of the folded cross-attention (key flag bit 28)
+only_tail = '--only-tail' in sys.argv     # re-time the 3x3 convolutions with a fused 1x1 skip (key flags: tc0 in bits 2..13)
 only_new = '--only-new' in sys.argv       # keep EVERY shipped pick, time only the shapes the table does not have yet (a new fusion's GEMMs)
 if os.path.exists(out):
     os.remove(out)
 os.makedirs(os.path.dirname(out), exist_ok=True)
-if only_quant or only_rows3 or only_ln or only_new or only_n160 or only_geglu or only_softmax:
+if only_quant or only_rows3 or only_ln or only_new or only_n160 or only_geglu or only_softmax or only_tail:
     shipped = os.path.join(ROOT, 'stable-diffusion-on-device_amd', 'tune', 'gfx950.tune')
     with open(shipped) as f, open(out, 'w') as g:
         for line in f:
@@ -37,6 +38,8 @@ if only_quant or only_rows3 or only_ln or only_new or only_n160 or only_geglu or
             # key fields (engine.hip: key_of): 0 a_mode, 6 stride, 8 ksize, 9 h_in, 10 flags (bit 29 = uint8 weights, bit 30 = LayerNorm fold)
             if only_new:
                 drop = False
+            elif only_tail:
+                drop = v[0] == '1' and ((int(v[10]) >> 2) & 4095) != 0 and not (int(v[10]) & (1 << 29))
             elif only_softmax:
                 drop = int(v[10]) & (1 << 28)
             elif only_geglu:
