@@ -96,6 +96,10 @@ SDOD_DEVICE float wave_max(float v) {
     return quad_rows_max(v);
 }
 
+// 1 / sqrt(x) for the statistics of the normalisation kernels: v_rsq_f32 (1 ulp) instead of an IEEE square root followed by an IEEE
+// division -- ~25 dependent instructions on the one lane every other lane of the group waits for
+SDOD_DEVICE float rsqrt_fast(float x) { return __builtin_amdgcn_rsqf(x); }
+
 SDOD_DEVICE f16x8 zero8() {
     f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     return z;

@@ -774,7 +774,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1)) void gemm_glds_kerne
                 var = var < 0.f ? 0.f : var;
                 const int r = (i * NL + lw) * 8 + lrow;
                 ln_stats[2 * r] = mean;
-                ln_stats[2 * r + 1] = 1.0f / sqrtf(var + p.ln_eps);
+                ln_stats[2 * r + 1] = rsqrt_fast(var + p.ln_eps);
             }
         }
     };
@@ -1484,7 +1484,7 @@ __global__ __launch_bounds__(768) void gemm_apanel_kernel(const GemmP p, const f
                         var = var < 0.f ? 0.f : var;
                         const int r = (i * NL + lw) * 8 + lrow;
                         ln_stats[2 * r] = mean;
-                        ln_stats[2 * r + 1] = 1.0f / sqrtf(var + p.ln_eps);
+                        ln_stats[2 * r + 1] = rsqrt_fast(var + p.ln_eps);
                     }
                 }
                 __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the statistics are in LDS before this wave meets the next barrier

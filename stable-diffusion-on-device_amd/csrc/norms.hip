@@ -186,11 +186,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnP p) {
             if (lane == 0) {
                 const float cnt = (float)p.HW * (float)p.Cg;
                 const float shift = p.shift[(size_t)n * p.G + g];
-                const float md = a / cnt;
-                float var = b / cnt - md * md;
+                const float icnt = __builtin_amdgcn_rcpf(cnt);
+                const float md = a * icnt;
+                float var = b * icnt - md * md;
                 var = var < 0.f ? 0.f : var;
                 gm[g] = shift + md;
-                gr[g] = 1.0f / sqrtf(var + p.eps);
+                gr[g] = rsqrt_fast(var + p.eps);
             }
         }
     }
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(NT) void gn_small_kernel(const GnP p, int sw) {
         float var = b * inv_cnt - md * md;
         var = var < 0.f ? 0.f : var;
         const float mean = (float)slab[gi * p.Cg] + md;
-        const float rstd = 1.0f / sqrtf(var + p.eps);
+        const float rstd = rsqrt_fast(var + p.eps);
         const int ch = cbase + c;
         const float w = c == tid ? pw : (p.w ? p.w[ch] : 1.0f), bb = c == tid ? pb : (p.b ? p.b[ch] : 0.0f);
         sc[c] = rstd * w;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(NT) void gn_group_kernel(const GnG p) {
         }
     }
     const float var = block_sum<NT>(s2, red, tid) * inv_cnt;
-    const float rstd = 1.0f / sqrtf(var + p.eps);
+    const float rstd = rsqrt_fast(var + p.eps);
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) pin(vals[k]);
 
@@ -727,11 +728,12 @@ __global__ __launch_bounds__(256) void gn2_apply_kernel(const Gn2P p) {
         b = oct_sum(b);
         if (l == 0) {
             const float cnt = (float)p.HW * (float)p.Cg;
-            const float md = a / cnt;
-            float var = b / cnt - md * md;
+            const float icnt = __builtin_amdgcn_rcpf(cnt);
+            const float md = a * icnt;
+            float var = b * icnt - md * md;
             var = var < 0.f ? 0.f : var;
             gm[g] = p.shift[(size_t)n * p.G + g] + md;
-            gr[g] = 1.0f / sqrtf(var + p.eps);
+            gr[g] = rsqrt_fast(var + p.eps);
         }
     }
     __syncthreads();
@@ -978,11 +980,12 @@ __global__ __launch_bounds__(512) void gn_grid_kernel(const GnGridP p) {
         b = group_sum<16>(b);
         if (g < p.G && l == 0) {
             const float cnt = (float)p.HW * (float)p.Cg;
-            const float md = a / cnt;
-            float var = b / cnt - md * md;
+            const float icnt = __builtin_amdgcn_rcpf(cnt);
+            const float md = a * icnt;
+            float var = b * icnt - md * md;
             var = var < 0.f ? 0.f : var;
             gm[g] = md; // + pilot, added below by the thread that holds it
-            gr[g] = 1.0f / sqrtf(var + p.eps);
+            gr[g] = rsqrt_fast(var + p.eps);
         }
     }
     __syncthreads();
@@ -1239,7 +1242,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const f16* x, f16* y, c
             }
         }
         sq = group_sum<LPR>(sq);
-        const float rstd = 1.0f / sqrtf(sq * inv_c + eps);
+        const float rstd = rsqrt_fast(sq * inv_c + eps);
         f16* yr = y + (size_t)(ok ? row : 0) * C;
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
@@ -1453,7 +1456,7 @@ __global__ __launch_bounds__(512) void gn_nchw_one_kernel(const GnNchwP p) {
             }
         }
     }
-    const float rstd = 1.0f / sqrtf(block_sum_512(sq, red) / (float)p.L + p.eps);
+    const float rstd = rsqrt_fast(block_sum_512(sq, red) / (float)p.L + p.eps);
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         const long long i = ((long long)k * 512 + threadIdx.x) * W;
@@ -1521,7 +1524,7 @@ __global__ __launch_bounds__(512) void gn_nchw_apply_kernel(const GnNchwP p) {
     const float md = s1 / (float)p.L;
     float var = s2 / (float)p.L - md * md;
     var = var < 0.f ? 0.f : var;
-    const float mean = shift + md, rstd = 1.0f / sqrtf(var + p.eps);
+    const float mean = shift + md, rstd = rsqrt_fast(var + p.eps);
     const long long i0 = (long long)blockIdx.x * p.per_chunk, i1 = min(p.L, i0 + p.per_chunk);
     if constexpr (VEC) {
         for (long long i = i0 + (long long)threadIdx.x * 8; i < i1; i += 512 * 8) {
