@@ -71,7 +71,7 @@ def kernel_symbol(label):
                 return f'gemm_apanel_kernel<{bm}, {bn}, {wm}, {wn}, {st}>', f'gemm_apanel_kernelILi{bm}ELi{bn}ELi{wm}ELi{wn}ELi{st}EE'
             return (f'gemm_glds_kernel<{bm}, {bn}, {wm}, {wn}, {st}, {"true" if spec else "false"}, false, {ksub}>',
                     f'gemm_glds_kernelILi{bm}ELi{bn}ELi{wm}ELi{wn}ELi{st}ELb{spec}ELb0ELi{ksub}EE')
-    plain = {'gn_group': 'gn_group_kernel<', 'gn_group_red': 'gn_group_kernel<', 'gn_grid': 'gn_grid_kernel<', 'gn_small': 'gn_small_kernel<', 'gn_stats_apply': 'gn_stats_kernel<', 'splitk_reduce': 'splitk_reduce_kernel',
+    plain = {'gn_group': 'gn_group_kernel<', 'gn_group_red': 'gn_group_kernel<', 'gn_grid': 'gn_grid_kernel<', 'gn_small': 'gn_small_kernel<', 'gn_stats_apply': 'gn_stats_kernel<', 'splitk_reduce': 'splitk_reduce_',
              'attn_d40': 'attn_kernel<40,', 'attn_d64': 'attn_kernel<64,', 'attn_d80': 'attn_kernel<80,', 'attn_d160': 'attn_kernel<160,',
              'layer_norm': 'layer_norm_kernel', 'softmax_rows': 'softmax_rows_kernel<'}
     return plain.get(label, label), None

@@ -2404,6 +2404,50 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
 #endif
 }
 
+// The reduce of every split-K plan in the graphs (whole quads, aligned vectors, bias per column): a workgroup is 64 quads x 4 rows
+// (no index divisions -- the general kernel below derives (m, n) from a 64-bit linear index, ~150 instructions in front of its
+// first load), every operand and four partial slabs are in flight before the first use, the slabs are added in slice order
+// (the bits of the general kernel and of the in-kernel fixup).
+__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmP p) {
+    const int n = ((int)blockIdx.x * 64 + (int)threadIdx.x) * 4;
+    const int m = (int)blockIdx.y * 4 + (int)threadIdx.y;
+    if (n >= p.N || m >= p.M) return;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float* src = p.partial + (size_t)m * p.N + n;
+    const size_t slab = (size_t)p.M * p.N;
+    const f32x4 b1 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
+    const f32x4 b2 = p.bias2 ? *reinterpret_cast<const f32x4*>(p.bias2 + n) : zero4;
+    f16x4 rb = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f}, rs = rb;
+    if (p.row_bias) rb = *reinterpret_cast<const f16x4*>(p.row_bias + (size_t)fast_div(m, p.mg_rpi, p.sh_rpi) * p.ldrb + n);
+    if (p.residual) rs = *reinterpret_cast<const f16x4*>(p.residual + (size_t)m * p.ldr + n);
+    f32x4 v = zero4;
+    int s = 0;
+    for (; s + 4 <= p.splits; s += 4) {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(src + (size_t)s * slab), t1 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 1) * slab);
+        const f32x4 t2 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 2) * slab), t3 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 3) * slab);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (((v[r] + t0[r]) + t1[r]) + t2[r]) + t3[r];
+    }
+    for (; s < p.splits; ++s) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + (size_t)s * slab);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += t[r];
+    }
+    f16x4 h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float f = v[r] * p.alpha;
+        if (p.bias) f += b1[r];
+        if (p.bias2) f += b2[r];
+        if (p.row_bias) f += (float)rb[r];
+        f = apply_act(f, p.act);
+        f = (float)(f16)f; // same rounding point as the un-split path
+        if (p.residual) f += (float)rs[r];
+        h[r] = (f16)f;
+    }
+    *reinterpret_cast<f16x4*>(p.out + (size_t)m * p.ldo + n) = h;
+}
+
 // Reduce split-K slabs and apply the fused epilogue.  One thread per 4 consecutive columns.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmP p) {
     const int n4 = (p.N + 3) / 4;
@@ -3162,10 +3206,17 @@ extern "C" int sdod_gemm_f16(const sdod_gemm_desc* d, void* stream) {
     }
     SDOD_HIP_CHECK(e);
     if (pl.splits > 1 && d->phase != 1 && !p.fixup) {
-        const size_t total = (size_t)d->M * ((d->N + 3) / 4);
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        SDOD_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+        const bool vec = (p.N % 4 == 0) && (p.ldo % 4 == 0) && !p.bias_on_m && (p.residual == nullptr || p.ldr % 4 == 0) &&
+                         (p.row_bias == nullptr || p.ldrb % 4 == 0) && (((uintptr_t)p.out | (uintptr_t)p.residual | (uintptr_t)p.row_bias) & 7) == 0 &&
+                         (((uintptr_t)p.bias | (uintptr_t)p.bias2 | (uintptr_t)p.partial) & 15) == 0 && (d->M + 3) / 4 <= 65535;
+        if (vec) {
+            SDOD_LAUNCH(splitk_reduce_vec_kernel, dim3((d->N / 4 + 63) / 64, (d->M + 3) / 4), dim3(64, 4), 0, st, p);
+        } else {
+            const size_t total = (size_t)d->M * ((d->N + 3) / 4);
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            SDOD_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+        }
         SDOD_HIP_CHECK(hipGetLastError());
     }
     return 0;

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r'(gemm_glds_kernel|conv_halo_kernel|gemm_apanel_kernel|attn_kernel|splitk_reduce_kernel|gn_\w+|\w+_kernel)', name)
+    m = re.search(r'(gemm_glds_kernel|conv_halo_kernel|gemm_apanel_kernel|attn_kernel|splitk_reduce_\w*kernel|gn_\w+|\w+_kernel)', name)
     return m.group(1) if m else name[:40]
 
 
