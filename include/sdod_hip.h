@@ -261,6 +261,13 @@ SDOD_API int sdod_im2col3x3_small_f16(const void* x, void* y, int n_img, int h, 
 /* sdod_latent_prep_f16 (w = NULL) followed by sdod_im2col3x3_small_f16 in one launch: x NCHW fp32 [n][c][h][w] -> the im2col matrix
  * [n*h*w][kpad] fp16 of a 3x3 pad-1 convolution (k = tap * c + channel, zero beyond 9c), values (fp16)(x * scale); kpad % 8 == 0 */
 SDOD_API int sdod_latent_im2col_f16(const float* x, void* y, int n_img, int h, int w, int c, int kpad, float scale, void* stream);
+
+/* The UNet's input convolution in one launch (the reference's /input_blocks.0/Conv, analyze_results.py:69-79): x NCHW fp32
+ * [n][c][h][w] (scaled by `scale`, rounded to fp16 as sdod_latent_im2col_f16 does) -> 3x3 pad-1 convolution with w fp16 [cout][64]
+ * (k = tap * c + channel, zero beyond 9 c: the PK_CONV3_SMALL packing) + bias fp32 [cout] -> y NHWC fp16 [n*h*w][cout].
+ * 9 * c <= 64; cout in {64, 128, 256, 320}.  Equals sdod_latent_im2col_f16 followed by the K = 64 sdod_gemm_f16. */
+SDOD_API int sdod_conv_in_f16(const float* x, const void* w, const float* bias, void* y, int n_img, int h, int wd, int c, int cout,
+                              float scale, void* stream);
 SDOD_API int sdod_nchw_f32_to_nhwc_f16(const float* x, void* y, int n, int c, int hw, float scale, void* stream);
 /* y(NHWC fp16)[img][pix][o] = sum_c w[o][c]*(scale*x(NCHW fp32)[img][c][pix]) + b[o]; w/b fp32 [c][c]/[c] or NULL
  * (identity).  Folds ldm's z/0.18215 and first_stage_model.post_quant_conv into the layout change. */

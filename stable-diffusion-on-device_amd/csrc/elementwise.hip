@@ -127,6 +127,84 @@ __global__ void latent_im2col_kernel(const float* x, f16* y, int n_img, int h, i
     }
 }
 
+// The UNet's input convolution (3x3 pad 1, Cin = 4 -> Cout = 320) in ONE launch: latent NCHW fp32 -> im2col rows (K = 9 Cin padded
+// to 64, the values latent_im2col_kernel writes) built straight in LDS, the whole [Cout][64] weight matrix next to them, one
+// v_mfma_f32_16x16x32_f16 pair per 16 x 16 output block, bias, NHWC fp16 out.  A workgroup owns 32 pixels x all Cout columns
+// (wave w: column blocks w, w + 4, ...): until now this was an im2col launch plus a K = 64 GEMM launch that is all prologue and
+// epilogue (7 + 10 us at 64x64).  Same products in the same order as the GEMM (two K steps), bias added in fp32.
+template <int NB> // 16-column blocks per wave: Cout = 64 * NB
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* x, const f16* w, const float* bias, f16* y, int n_img, int h, int wd, int c,
+                                                      float scale) {
+    __shared__ __attribute__((aligned(16))) f16 sa[32][64 + 8];
+    __shared__ __attribute__((aligned(16))) f16 sw[64 * NB][64 + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cout = 64 * NB, hw = h * wd;
+    const long long m0 = (long long)blockIdx.x * 32, M = (long long)n_img * hw;
+    // weights: 8 pieces of 16 bytes per row
+    for (int idx = tid; idx < cout * 8; idx += 256) {
+        const int r = idx >> 3, ch = idx & 7;
+        *reinterpret_cast<f16x8*>(&sw[r][ch * 8]) = ldg8(w + (size_t)r * 64 + ch * 8);
+    }
+    // im2col rows: thread = (pixel, 8 consecutive k)
+    {
+        const int pl = tid >> 3, k0 = (tid & 7) * 8;
+        const long long m = m0 + pl;
+        f16x8 v = zero8();
+        if (m < M) {
+            const int img = (int)(m / hw), rem = (int)(m - (long long)img * hw);
+            const int oy = rem / wd, ox = rem - oy * wd;
+            int tap = k0 / c, ch = k0 - tap * c; // one division per thread; (tap, channel) then advance by increments
+            const float* xi = x + (size_t)img * c * hw;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = 0.f;
+                if (tap < 9) {
+                    const int r = (tap * 11) >> 5, s2 = tap - r * 3; // tap / 3 for tap < 9
+                    const int yy = oy + r - 1, xx = ox + s2 - 1;
+                    if (yy >= 0 && yy < h && xx >= 0 && xx < wd) f = 0.f + xi[(size_t)ch * hw + yy * wd + xx] * scale;
+                }
+                v[e] = (f16)f;
+                if (++ch == c) { ch = 0; ++tap; }
+            }
+        }
+        *reinterpret_cast<f16x8*>(&sa[pl][k0]) = v;
+    }
+    __syncthreads();
+    const int fr = lane & 15, fg = lane >> 4;
+    f32x4 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        f16x8 fa[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f16x8*>(&sa[i * 16 + fr][ks * 32 + fg * 8]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const f16x8 fb = *reinterpret_cast<const f16x8*>(&sw[(j * 4 + wave) * 16 + fr][ks * 32 + fg * 8]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = mfma16(fb, fa[i], acc[i][j]); // lane: row i*16 + fr, columns (j*4+wave)*16 + 4 fg + r
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = (j * 4 + wave) * 16 + fg * 4;
+        const f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long m = m0 + i * 16 + fr;
+            if (m < M) {
+                f16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (f16)(acc[i][j][r] + b[r]);
+                *reinterpret_cast<f16x4*>(y + (size_t)m * cout + n) = o;
+            }
+        }
+    }
+}
+
 __global__ void nchw_to_nhwc_kernel(const float* x, f16* y, int n, int c, int hw, float scale) {
     const size_t total = (size_t)n * c * hw;
     GRID_STRIDE(i, total) { // i indexes the NHWC output
@@ -510,6 +588,26 @@ extern "C" int sdod_latent_im2col_f16(const float* x, void* y, int n_img, int h,
     SDOD_TRY
     SDOD_REQUIRE(x && y && n_img > 0 && h > 0 && w > 0 && c > 0 && kpad >= 9 * c && kpad % 8 == 0 && ((uintptr_t)y & 15) == 0, "bad argument");
     LAUNCH(latent_im2col_kernel, (size_t)n_img * h * w * (kpad / 8), stream, x, (f16*)y, n_img, h, w, c, kpad, scale);
+    return 0;
+    SDOD_CATCH
+}
+
+extern "C" int sdod_conv_in_f16(const float* x, const void* w, const float* bias, void* y, int n_img, int h, int wd, int c, int cout,
+                                float scale, void* stream) {
+    SDOD_TRY
+    SDOD_REQUIRE(x && w && y && n_img > 0 && h > 0 && wd > 0 && c > 0 && 9 * c <= 64, "bad argument (9 * Cin must fit the 64-deep K slab)");
+    SDOD_REQUIRE(cout == 320 || cout == 256 || cout == 128 || cout == 64, "Cout must be 64, 128, 256 or 320");
+    SDOD_REQUIRE((((uintptr_t)w | (uintptr_t)bias) & 15) == 0 && ((uintptr_t)y & 7) == 0, "misaligned pointer");
+    const long long M = (long long)n_img * h * wd;
+    const dim3 grid((unsigned)((M + 31) / 32));
+    hipStream_t st = (hipStream_t)stream;
+    switch (cout / 64) {
+    case 1: SDOD_LAUNCH(conv_in_kernel<1>, grid, dim3(256), 0, st, x, (const f16*)w, bias, (f16*)y, n_img, h, wd, c, scale); break;
+    case 2: SDOD_LAUNCH(conv_in_kernel<2>, grid, dim3(256), 0, st, x, (const f16*)w, bias, (f16*)y, n_img, h, wd, c, scale); break;
+    case 4: SDOD_LAUNCH(conv_in_kernel<4>, grid, dim3(256), 0, st, x, (const f16*)w, bias, (f16*)y, n_img, h, wd, c, scale); break;
+    default: SDOD_LAUNCH(conv_in_kernel<5>, grid, dim3(256), 0, st, x, (const f16*)w, bias, (f16*)y, n_img, h, wd, c, scale); break;
+    }
+    SDOD_HIP_CHECK(hipGetLastError());
     return 0;
     SDOD_CATCH
 }

@@ -333,11 +333,25 @@ void Graph::build_unet() {
 
     // input conv (Cin = 4): im2col to K = 64, then the GEMM
     const int ciw = P("input_blocks.0.0.weight", {MC, LC, 3, 3}, PK_CONV3_SMALL), cib = P("input_blocks.0.0.bias", {MC}, PK_VEC);
-    f16* cols = alloc((size_t)B * H * Wd * 64);
-    emit([=](hipStream_t st) { check_rc2(sdod_latent_im2col_f16(x_in, cols, B, H, Wd, LC, 64, 1.0f, st)); });
     Act h = act(B, H, Wd, MC);
-    { GemmOpt o; o.bias = cib; linear(cols, B * H * Wd, 64, ciw, MC, h.p, o); }
-    release(cols);
+    if (MC == 320 || MC == 256 || MC == 128 || MC == 64) {
+        // ONE launch: im2col rows built in LDS, the whole [MC][64] weight matrix next to them (elementwise.hip: conv_in_kernel)
+        const f16* wp = mode_ != DECLARE ? W<f16>(ciw) : nullptr;
+        const float* bp = mode_ != DECLARE ? W<float>(cib) : nullptr;
+        f16* hp = h.p;
+        settle();
+        if (mode_ == REAL) {
+            flops_ += 2.0 * B * H * Wd * MC * 64;
+            ops_.push_back(Op{[=](hipStream_t st) { check_rc2(sdod_conv_in_f16(x_in, wp, bp, hp, B, H, Wd, LC, MC, 1.0f, st)); }, "conv_in",
+                              2.0 * B * H * Wd * MC * 64, (double)B * H * Wd * (LC * 4 + MC * 2) + MC * 64 * 2,
+                              "M" + std::to_string(B * H * Wd) + " N" + std::to_string(MC) + " K64"});
+        }
+    } else {
+        f16* cols = alloc((size_t)B * H * Wd * 64);
+        emit([=](hipStream_t st) { check_rc2(sdod_latent_im2col_f16(x_in, cols, B, H, Wd, LC, 64, 1.0f, st)); });
+        { GemmOpt o; o.bias = cib; linear(cols, B * H * Wd, 64, ciw, MC, h.p, o); }
+        release(cols);
+    }
 
     std::vector<Act> hs;
     hs.push_back(h);

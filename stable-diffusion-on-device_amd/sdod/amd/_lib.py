@@ -117,6 +117,7 @@ def _declare(lib):
         'sdod_concat_channels_f16': (c_int, [P, P, P, c_size_t, c_int, c_int, P]),
         'sdod_im2col3x3_small_f16': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
         'sdod_latent_im2col_f16': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+        'sdod_conv_in_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
         'sdod_plms_update': (c_int, [ctypes.POINTER(PlmsUpdateArgs), P]),
         'sdod_dpm_step': (c_int, [ctypes.POINTER(DpmStepArgs), P]),
         'sdod_nchw_f32_to_nhwc_f16': (c_int, [P, P, c_int, c_int, c_int, c_float, P]),
@@ -143,7 +144,7 @@ def _declare(lib):
 HIP_SYMBOLS = [
     'sdod_gemm_f16', 'sdod_gemm_fixup', 'sdod_gemm_fixup_counters', 'sdod_gemm_workspace_bytes', 'sdod_gemm_plan', 'sdod_gemm_halo_ok', 'sdod_gemm_panel_ok', 'sdod_gemm_xcd_panels', 'sdod_gemm_num_tiles', 'sdod_gemm_tile_shape', 'sdod_gemm_tile_info', 'sdod_gemm_time', 'sdod_gemm_time_cold', 'sdod_group_norm_workspace_bytes', 'sdod_group_norm_layout', 'sdod_group_norm_status', 'sdod_group_norm_clear_error', 'sdod_l2_prefetch', 'sdod_group_norm_launches', 'sdod_group_norm_path', 'sdod_group_norm_nhwc', 'sdod_group_norm_nchw', 'sdod_group_norm_nchw_workspace_bytes', 'sdod_gemm_reduce_info', 'sdod_group_norm_reduce_ok', 'sdod_group_norm_reduce_nhwc',
     'sdod_layer_norm_f16', 'sdod_ln_fold_f16', 'sdod_compose_linear_f16', 'sdod_attention_f16', 'sdod_xattn_fold_f16', 'sdod_softmax_rows_f16', 'sdod_geglu_f16', 'sdod_act_f16',
-    'sdod_add_f16', 'sdod_concat_channels_f16', 'sdod_im2col3x3_small_f16', 'sdod_latent_im2col_f16', 'sdod_plms_update', 'sdod_dpm_step', 'sdod_nchw_f32_to_nhwc_f16',
+    'sdod_add_f16', 'sdod_concat_channels_f16', 'sdod_im2col3x3_small_f16', 'sdod_latent_im2col_f16', 'sdod_conv_in_f16', 'sdod_plms_update', 'sdod_dpm_step', 'sdod_nchw_f32_to_nhwc_f16',
     'sdod_nhwc_f16_to_nchw_f32', 'sdod_latent_prep_f16', 'sdod_embedding_f16', 'sdod_timestep_features_f16', 'sdod_cfg_combine', 'sdod_stage_unet_inputs', 'sdod_randn_f32',
     'sdod_dpm_update', 'sdod_ddim_step_f32', 'sdod_lincomb4_f32', 'sdod_image_to_u8', 'sdod_hip_last_error',
     'sdod_hip_device_info',

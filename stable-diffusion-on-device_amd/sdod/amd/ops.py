@@ -356,6 +356,19 @@ def latent_im2col(x, kpad=64, scale=1.0):
     return out
 
 
+def conv_in(x, w, bias, scale=1.0):
+    """the UNet's input convolution in one launch (include/sdod_hip.h: sdod_conv_in_f16): x NCHW fp32 [n, c, h, w], w fp16
+    [cout, 64] (k = tap * c + channel, zero beyond 9 c), bias fp32 [cout] -> NHWC fp16 [n, h, w, cout]"""
+    lib = _lib.hip()
+    _req(x, torch.float32, 'x'); _req(w, torch.float16, 'w'); _req(bias, torch.float32, 'bias')
+    n, c, h, wd = x.shape
+    cout = w.shape[0]
+    assert w.shape[1] == 64
+    out = torch.empty((n, h, wd, cout), dtype=torch.float16, device=x.device)
+    check(lib.sdod_conv_in_f16(_p(x), _p(w), _p(bias), _p(out), n, h, wd, c, cout, scale, _stream()))
+    return out
+
+
 def nchw_f32_to_nhwc_f16(x, scale=1.0):
     lib = _lib.hip()
     _req(x, torch.float32, 'x')

@@ -1113,3 +1113,23 @@ def test_dpm_step_equals_the_three_launches(order, stage, uncond_first):
     assert torch.equal(xf, xr) and torch.equal(yf, yr)
     if stage:
         assert torch.equal(xs, xs_ref) and torch.equal(ts, ts_ref)
+
+
+@pytest.mark.parametrize('n,h,w,cout', [(2, 64, 64, 320), (1, 17, 9, 320), (3, 8, 8, 128), (2, 96, 96, 320)])
+def test_conv_in_equals_im2col_then_gemm(n, h, w, cout):
+    """sdod_conv_in_f16 (the UNet's input convolution in one launch: im2col rows built in LDS + the K = 64 product) against the two
+    launches it replaces (sdod_latent_im2col_f16 -> sdod_gemm_f16): the same fp16 operands, the same two MFMA K steps, bias in
+    fp32 -- and against the fp32 convolution"""
+    from sdod.amd import ops
+    g = torch.Generator().manual_seed(n * 1000 + h)
+    x = torch.randn(n, 4, h, w, generator=g).cuda()
+    wt = (torch.randn(cout, 4, 3, 3, generator=g) / 6).half()
+    bias = torch.randn(cout, generator=g).cuda()
+    wk = torch.zeros(cout, 64, dtype=torch.float16)
+    wk[:, :36] = wt.permute(0, 2, 3, 1).reshape(cout, 36)              # k = tap * c + channel
+    wk = wk.cuda()
+    out = ops.conv_in(x, wk, bias)
+    two = ops.gemm(ops.latent_im2col(x, 64, 1.0), wk, bias).view(n, h, w, cout)
+    assert torch.equal(out, two)
+    ref = F.conv2d(x.half().float().cpu(), wt.float(), bias.cpu(), padding=1).permute(0, 2, 3, 1)
+    check(out, ref, name=f'conv_in {n}x{h}x{w} -> {cout}')
