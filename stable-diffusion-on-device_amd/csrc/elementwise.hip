@@ -140,11 +140,11 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* x, const f16*
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cout = 64 * NB, hw = h * wd;
     const long long m0 = (long long)blockIdx.x * 32, M = (long long)n_img * hw;
-    // weights: 8 pieces of 16 bytes per row
-    for (int idx = tid; idx < cout * 8; idx += 256) {
-        const int r = idx >> 3, ch = idx & 7;
-        *reinterpret_cast<f16x8*>(&sw[r][ch * 8]) = ldg8(w + (size_t)r * 64 + ch * 8);
-    }
+    // weights: 8 pieces of 16 bytes per row, 2 NB pieces per thread -- all requested before the first is stored (one memory round
+    // trip, not 2 NB of them)
+    f16x8 wv[2 * NB];
+#pragma unroll
+    for (int i = 0; i < 2 * NB; ++i) wv[i] = ldg8(w + (size_t)(tid + 256 * i) * 8);
     // im2col rows: thread = (pixel, 8 consecutive k)
     {
         const int pl = tid >> 3, k0 = (tid & 7) * 8;
@@ -168,6 +168,11 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* x, const f16*
             }
         }
         *reinterpret_cast<f16x8*>(&sa[pl][k0]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * NB; ++i) {
+        const int idx = tid + 256 * i;
+        *reinterpret_cast<f16x8*>(&sw[idx >> 3][(idx & 7) * 8]) = wv[i];
     }
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;

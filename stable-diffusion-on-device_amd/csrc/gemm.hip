@@ -1828,6 +1828,31 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmP p, const f16
     auto store_phase = [&](int nthr) { // nthr = threads of the workgroup still alive (512; 256 behind an in-kernel split-K fixup)
         constexpr int CPR = BN / 8; // 16-byte chunks per output tile row
         const bool vec_ok = (p.N % 8 == 0) && (p.ldo % 8 == 0) && (p.residual == nullptr || p.ldr % 8 == 0);
+        if (vec_ok && p.residual != nullptr && nthr == 512) {
+            // every residual piece of the thread requested before the first is used: the loop below fetches one per trip and
+            // waits for it (a memory round trip per trip, three or four of them at the tail of every ResBlock's second convolution)
+            constexpr int IT = (BM * CPR + 511) / 512;
+            f16x8 rr[IT];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int idx = tid + it * 512;
+                const int row = idx / CPR, ch = idx - row * CPR;
+                const int m = m0 + row, n = n0 + ch * 8;
+                rr[it] = (idx < BM * CPR && m < p.M && n < p.N) ? ldg8(p.residual + (size_t)m * p.ldr + n) : zero8();
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int idx = tid + it * 512;
+                const int row = idx / CPR, ch = idx - row * CPR;
+                const int m = m0 + row, n = n0 + ch * 8;
+                if (idx >= BM * CPR || m >= p.M || n >= p.N) continue;
+                f16x8 v = *reinterpret_cast<const f16x8*>(sC + row * SC + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)rr[it][e]);
+                stg8(p.out + (size_t)m * p.ldo + n, v);
+            }
+            return;
+        }
         for (int idx = tid; idx < BM * CPR; idx += nthr) {
             const int row = idx / CPR;
             const int ch = idx - row * CPR;
